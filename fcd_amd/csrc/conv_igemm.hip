@@ -1,0 +1,662 @@
+// Implicit-GEMM convolutions on the gfx950 matrix cores.
+//
+//   conv_gather_kernel  out[pixel][co] = sum_k in[gather(pixel, k)][.] * w[co][k]
+//                       (forward conv, transposed conv by 4 phases, data gradients)
+//   conv_wgrad_kernel   dw[o][tap,i]   = sum_pixel gs[pixel][o] * xb[gather(pixel,tap)][i]
+//
+// Both stage their operand tiles through LDS with 16-byte loads and feed
+// v_mfma_f32_32x32x2_f32 (exact fp32 fma chain) or v_mfma_f32_32x32x16_bf16
+// (operands rounded to bf16 while staging, fp32 accumulate).  A workgroup is 4
+// wavefronts of 64 lanes; each wave owns a (BM/WM) x (BN/WN) block of 32x32
+// accumulator tiles.  Split-K partial sums go to caller-provided slabs and are
+// combined in a fixed order by a second kernel, so results are bitwise
+// reproducible run to run.
+#include "fcd_common.h"
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+namespace {
+
+struct GatherArgs {
+  const float* in;
+  const float* w;
+  const float* bias;
+  const float* mask;
+  const float* res;
+  float* out;
+  float* slab;
+  int N, IH, IW, Cin, GH, GW, OH, OW, Cout, CoutP, KH, KW, K;
+  int istride, ostride, nphase, splitk;
+  int pad_h[4], pad_w[4], ooff_h[4], ooff_w[4];
+  int M, ktiles, ktiles_per_split, tiles_m, tiles_n;
+  long w_phase_stride;
+  float act_slope, mask_slope;
+};
+
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+  unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
+  ua = (ua + 0x7FFFu + ((ua >> 16) & 1u)) >> 16;
+  ub = (ub + 0x7FFFu + ((ub >> 16) & 1u)) & 0xFFFF0000u;
+  return ua | ub;
+}
+
+__device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+__device__ __forceinline__ float epilogue_value(float v, int co, long o, const GatherArgs& p) {
+  if (p.bias) v += p.bias[co];
+  v = v > 0.f ? v : v * p.act_slope;
+  if (p.mask) v *= (p.mask[o] > 0.f ? 1.f : p.mask_slope);
+  if (p.res) v += p.res[o];
+  return v;
+}
+
+// One 16-byte LDS chunk holds KPC consecutive k: 4 fp32 or 8 bf16.  A K tile is 8 chunks per
+// row; chunk c of row r lives at slot c ^ ((r >> 1) & 7) so that the 16 rows a ds_read_b128
+// lane group touches fall on 16 different 16-byte bank slots.
+template <int BM, int BN, int WM, int WN, bool BF16>
+__global__ __launch_bounds__(256) void conv_gather_kernel(const GatherArgs p) {
+  constexpr int KPC = BF16 ? 8 : 4;       // k per chunk
+  constexpr int BK = 8 * KPC;             // k per tile
+  constexpr int NG = BF16 ? 2 : 1;        // float4 global loads per chunk
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int AL = BM / 32, BL = BN / 32;  // chunks per thread per tile
+  static_assert(WM * WN == 4, "4 waves");
+
+  __shared__ float4 As[BM * 8];
+  __shared__ float4 Bs[BN * 8];
+  __shared__ long rowoff[BM];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int tn = blockIdx.x % p.tiles_n, tm = blockIdx.x / p.tiles_n;
+  const int phase = blockIdx.y / p.splitk, ks = blockIdx.y % p.splitk;
+  const int pad_h = p.pad_h[phase], pad_w = p.pad_w[phase];
+  const float* __restrict__ wph = p.w + (long)phase * p.w_phase_stride;
+
+  const int ghw = p.GH * p.GW;
+  // output offsets of this tile's rows (or -1)
+  for (int r = tid; r < BM; r += 256) {
+    const int m = tm * BM + r;
+    long off = -1;
+    if (m < p.M) {
+      const int n = m / ghw, rem = m - n * ghw;
+      const int a = rem / p.GW, b = rem - a * p.GW;
+      if (p.splitk > 1) {
+        off = (long)m * p.CoutP;
+      } else {
+        off = (((long)n * p.OH + a * p.ostride + p.ooff_h[phase]) * p.OW + b * p.ostride +
+               p.ooff_w[phase]) * p.CoutP;
+      }
+    }
+    rowoff[r] = off;
+  }
+
+  // rows this thread gathers: r = (tid >> 3) + 32*i, chunk kc = tid & 7
+  const int kc = tid & 7, r0 = tid >> 3;
+  int a_ih0[AL], a_iw0[AL];
+  long a_base[AL];
+#pragma unroll
+  for (int i = 0; i < AL; ++i) {
+    const int m = tm * BM + r0 + 32 * i;
+    if (m < p.M) {
+      const int n = m / ghw, rem = m - n * ghw;
+      const int a = rem / p.GW, b = rem - a * p.GW;
+      a_ih0[i] = a * p.istride - pad_h;
+      a_iw0[i] = b * p.istride - pad_w;
+      a_base[i] = (long)n * p.IH * p.IW;
+    } else {
+      a_ih0[i] = -(1 << 28);
+      a_iw0[i] = 0;
+      a_base[i] = 0;
+    }
+  }
+
+  float4 areg[AL][NG], breg[BL][NG];
+
+  auto load_tile = [&](int kt) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const int k = kt * BK + kc * KPC + g * 4;
+      const bool kok = k < p.K;
+      const int tap = k / p.Cin, ci = k - tap * p.Cin;
+      const int th = tap / p.KW, tw = tap - th * p.KW;
+#pragma unroll
+      for (int i = 0; i < AL; ++i) {
+        const int ih = a_ih0[i] + th, iw = a_iw0[i] + tw;
+        const bool ok = kok && ih >= 0 && ih < p.IH && iw >= 0 && iw < p.IW;
+        areg[i][g] = ok ? ldg4(p.in + (a_base[i] + (long)ih * p.IW + iw) * p.Cin + ci)
+                        : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int i = 0; i < BL; ++i) {
+        const int co = tn * BN + r0 + 32 * i;
+        const bool ok = kok && co < p.Cout;
+        breg[i][g] = ok ? ldg4(wph + (long)co * p.K + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  };
+
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < AL; ++i) {
+      const int r = r0 + 32 * i;
+      float4 v;
+      if constexpr (BF16) {
+        v.x = __uint_as_float(pack_bf16x2(areg[i][0].x, areg[i][0].y));
+        v.y = __uint_as_float(pack_bf16x2(areg[i][0].z, areg[i][0].w));
+        v.z = __uint_as_float(pack_bf16x2(areg[i][NG - 1].x, areg[i][NG - 1].y));
+        v.w = __uint_as_float(pack_bf16x2(areg[i][NG - 1].z, areg[i][NG - 1].w));
+      } else {
+        v = areg[i][0];
+      }
+      As[r * 8 + (kc ^ ((r >> 1) & 7))] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < BL; ++i) {
+      const int r = r0 + 32 * i;
+      float4 v;
+      if constexpr (BF16) {
+        v.x = __uint_as_float(pack_bf16x2(breg[i][0].x, breg[i][0].y));
+        v.y = __uint_as_float(pack_bf16x2(breg[i][0].z, breg[i][0].w));
+        v.z = __uint_as_float(pack_bf16x2(breg[i][NG - 1].x, breg[i][NG - 1].y));
+        v.w = __uint_as_float(pack_bf16x2(breg[i][NG - 1].z, breg[i][NG - 1].w));
+      } else {
+        v = breg[i][0];
+      }
+      Bs[r * 8 + (kc ^ ((r >> 1) & 7))] = v;
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int kt0 = ks * p.ktiles_per_split;
+  const int kt1 = min(p.ktiles, kt0 + p.ktiles_per_split);
+  const int lr = lane & 31, lh = lane >> 5;
+
+  if (kt0 < kt1) {
+    load_tile(kt0);
+    store_tile();
+  }
+  __syncthreads();
+
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const bool more = kt + 1 < kt1;
+    if (more) load_tile(kt + 1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float4 af[TM], bf[TN];
+      const int c = 2 * j + lh;
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi) {
+        const int r = wm * WTM + mi * 32 + lr;
+        af[mi] = As[r * 8 + (c ^ ((r >> 1) & 7))];
+      }
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni) {
+        const int r = wn * WTN + ni * 32 + lr;
+        bf[ni] = Bs[r * 8 + (c ^ ((r >> 1) & 7))];
+      }
+      if constexpr (BF16) {
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < TN; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                __builtin_bit_cast(bf16x8_t, af[mi]), __builtin_bit_cast(bf16x8_t, bf[ni]),
+                acc[mi][ni], 0, 0, 0);
+      } else {
+        // lane half h supplies k = 8j + 4h + e for element e: pairs (e, 4 + e) per MFMA
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < TN; ++ni) {
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].x, bf[ni].x, acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].y, bf[ni].y, acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].z, bf[ni].z, acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].w, bf[ni].w, acc[mi][ni], 0, 0, 0);
+          }
+      }
+    }
+    __syncthreads();
+    if (more) {
+      store_tile();
+      __syncthreads();
+    }
+  }
+
+  // epilogue: D[row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)][col = lane&31]
+  float* __restrict__ dst = p.splitk > 1 ? p.slab + (long)blockIdx.y * p.M * p.CoutP : p.out;
+#pragma unroll
+  for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) {
+      const int co = tn * BN + wn * WTN + ni * 32 + lr;
+      if (co >= p.CoutP) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * WTM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const long off = rowoff[row];
+        if (off < 0) continue;
+        float v = acc[mi][ni][r];
+        if (p.splitk == 1) v = co < p.Cout ? epilogue_value(v, co, off + co, p) : 0.f;
+        dst[off + co] = v;
+      }
+    }
+}
+
+// Sum the split-K slabs in a fixed order, apply the epilogue, scatter to the output pixels.
+__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const GatherArgs p) {
+  const long total = (long)p.nphase * p.M * p.CoutP;
+  const int ghw = p.GH * p.GW;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int co = (int)(idx % p.CoutP);
+    const long pm = idx / p.CoutP;
+    const int m = (int)(pm % p.M), phase = (int)(pm / p.M);
+    float v = 0.f;
+    for (int s = 0; s < p.splitk; ++s)
+      v += p.slab[((long)(phase * p.splitk + s) * p.M + m) * p.CoutP + co];
+    const int n = m / ghw, rem = m - n * ghw;
+    const int a = rem / p.GW, b = rem - a * p.GW;
+    const long o = (((long)n * p.OH + a * p.ostride + p.ooff_h[phase]) * p.OW + b * p.ostride +
+                    p.ooff_w[phase]) * p.CoutP + co;
+    p.out[o] = co < p.Cout ? epilogue_value(v, co, o, p) : 0.f;
+  }
+}
+
+// --------------------------------------------------------------------------------------------
+struct WgradArgs {
+  const float* gs;   // [P][OP]
+  const float* xb;   // [N][BH][BW][IP]
+  float* slab;       // [splitk][O][ND]
+  float* dw;         // [O][I][KH][KW]
+  int N, GH, GW, O, OP, BH, BW, I, IP, KH, KW, stride, pad;
+  int P, ND, splitk, ktiles, ktiles_per_split, tiles_m, tiles_n, accumulate;
+};
+
+template <int BM, int BN, int WM, int WN, bool BF16>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
+  // K runs over pixels; both operand tiles are [pixel][column] in memory and in LDS.
+  constexpr int BK = 32;
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int ACOLS = BM / 4, BCOLS = BN / 4;          // float4 columns
+  constexpr int AROWS = 256 / ACOLS, BROWS = 256 / BCOLS;  // pixel rows per pass
+  constexpr int AL = BK / AROWS, BL = BK / BROWS;
+  constexpr int LDA = BM + 4, LDB = BN + 4;   // +4 floats: lane halves land on different banks
+
+  __shared__ float As[BK * LDA];
+  __shared__ float Bs[BK * LDB];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int tn = blockIdx.x % p.tiles_n, tm = blockIdx.x / p.tiles_n;
+  const int ks = blockIdx.y;
+  const int ghw = p.GH * p.GW;
+
+  const int acol = tid % ACOLS, arow0 = tid / ACOLS;
+  const int bcol = tid % BCOLS, brow0 = tid / BCOLS;
+  const int o0 = tm * BM + acol * 4;
+  const bool a_ok = o0 < p.OP;
+  const int nd = tn * BN + bcol * 4;
+  const bool b_ok = nd < p.ND;
+  const int tap = nd / p.IP, ci = nd - tap * p.IP;
+  const int th = tap / p.KW, tw = tap - th * p.KW;
+
+  float4 areg[AL], breg[BL];
+
+  auto load_tile = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < AL; ++i) {
+      const int px = kt * BK + arow0 + AROWS * i;
+      areg[i] = (a_ok && px < p.P) ? ldg4(p.gs + (long)px * p.OP + o0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < BL; ++i) {
+      const int px = kt * BK + brow0 + BROWS * i;
+      bool ok = b_ok && px < p.P;
+      long off = 0;
+      if (ok) {
+        const int n = px / ghw, rem = px - n * ghw;
+        const int a = rem / p.GW, b = rem - a * p.GW;
+        const int ih = a * p.stride - p.pad + th, iw = b * p.stride - p.pad + tw;
+        ok = ih >= 0 && ih < p.BH && iw >= 0 && iw < p.BW;
+        off = (((long)n * p.BH + ih) * p.BW + iw) * p.IP + ci;
+      }
+      breg[i] = ok ? ldg4(p.xb + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < AL; ++i)
+      *reinterpret_cast<float4*>(&As[(arow0 + AROWS * i) * LDA + acol * 4]) = areg[i];
+#pragma unroll
+    for (int i = 0; i < BL; ++i)
+      *reinterpret_cast<float4*>(&Bs[(brow0 + BROWS * i) * LDB + bcol * 4]) = breg[i];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int kt0 = ks * p.ktiles_per_split;
+  const int kt1 = min(p.ktiles, kt0 + p.ktiles_per_split);
+  const int lr = lane & 31, lh = lane >> 5;
+
+  if (kt0 < kt1) {
+    load_tile(kt0);
+    store_tile();
+  }
+  __syncthreads();
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const bool more = kt + 1 < kt1;
+    if (more) load_tile(kt + 1);
+    if constexpr (BF16) {
+      // bf16: lane half h needs k = 8h..8h+7 of a 16-pixel step; gather them from 8 LDS rows
+#pragma unroll
+      for (int j = 0; j < BK / 16; ++j) {
+        unsigned au[TM][4], bu[TN][4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int k = j * 16 + lh * 8 + e * 2;
+#pragma unroll
+          for (int mi = 0; mi < TM; ++mi) {
+            const int c = wm * WTM + mi * 32 + lr;
+            au[mi][e] = pack_bf16x2(As[k * LDA + c], As[(k + 1) * LDA + c]);
+          }
+#pragma unroll
+          for (int ni = 0; ni < TN; ++ni) {
+            const int c = wn * WTN + ni * 32 + lr;
+            bu[ni][e] = pack_bf16x2(Bs[k * LDB + c], Bs[(k + 1) * LDB + c]);
+          }
+        }
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < TN; ++ni) {
+            uint4 ua = make_uint4(au[mi][0], au[mi][1], au[mi][2], au[mi][3]);
+            uint4 ub = make_uint4(bu[ni][0], bu[ni][1], bu[ni][2], bu[ni][3]);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                __builtin_bit_cast(bf16x8_t, ua), __builtin_bit_cast(bf16x8_t, ub), acc[mi][ni], 0, 0, 0);
+          }
+      }
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < BK / 2; ++kk) {
+        float af[TM], bf[TN];
+        const int k = 2 * kk + lh;
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) af[mi] = As[k * LDA + wm * WTM + mi * 32 + lr];
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) bf[ni] = Bs[k * LDB + wn * WTN + ni * 32 + lr];
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < TN; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+    if (more) {
+      store_tile();
+      __syncthreads();
+    }
+  }
+
+  float* __restrict__ dst = p.slab + (long)ks * p.O * p.ND;
+#pragma unroll
+  for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) {
+      const int col = tn * BN + wn * WTN + ni * 32 + lr;
+      if (col >= p.ND) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = tm * BM + wm * WTM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (o < p.O) dst[(long)o * p.ND + col] = acc[mi][ni][r];
+      }
+    }
+}
+
+// slabs [splitk][O][KH*KW*IP] -> parameter layout [O][I][KH][KW]
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs p) {
+  const int taps = p.KH * p.KW;
+  const long total = (long)p.O * p.I * taps;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    // read-coalesced order: idx -> (o, tap, i)
+    const int i = (int)(idx % p.I);
+    const long t2 = idx / p.I;
+    const int tap = (int)(t2 % taps), o = (int)(t2 / taps);
+    float v = 0.f;
+    for (int s = 0; s < p.splitk; ++s) v += p.slab[((long)s * p.O + o) * p.ND + tap * p.IP + i];
+    const long d = ((long)o * p.I + i) * taps + tap;
+    p.dw[d] = p.accumulate ? p.dw[d] + v : v;
+  }
+}
+
+__global__ __launch_bounds__(256) void pack_fwd_kernel(const float* __restrict__ w, float* __restrict__ out,
+                                                       int O, int I, int IP, int taps) {
+  const long total = (long)O * taps * IP;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int i = (int)(idx % IP);
+    const long t2 = idx / IP;
+    const int tap = (int)(t2 % taps), o = (int)(t2 / taps);
+    out[idx] = i < I ? w[((long)o * I + i) * taps + tap] : 0.f;
+  }
+}
+
+// out[phase][i][th][tw][o]
+__global__ __launch_bounds__(256) void pack_adj_kernel(const float* __restrict__ w, float* __restrict__ out,
+                                                       int O, int OP, int I, int KH, int KW, int stride) {
+  const int TH = stride == 1 ? KH : 2, TW = stride == 1 ? KW : 2;
+  const int nph = stride == 1 ? 1 : 4;
+  const long total = (long)nph * I * TH * TW * OP;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int o = (int)(idx % OP);
+    long t = idx / OP;
+    const int tw = (int)(t % TW); t /= TW;
+    const int th = (int)(t % TH); t /= TH;
+    const int i = (int)(t % I);
+    const int ph = (int)(t / I);
+    int kh, kw;
+    if (stride == 1) {
+      kh = KH - 1 - th;
+      kw = KW - 1 - tw;
+    } else {
+      const int py = ph >> 1, px = ph & 1;
+      kh = 3 - py - 2 * th;
+      kw = 3 - px - 2 * tw;
+    }
+    out[idx] = o < O ? w[(((long)o * I + i) * KH + kh) * KW + kw] : 0.f;
+  }
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_gather(const GatherArgs& a, int precision, hipStream_t st) {
+  dim3 grid(a.tiles_m * a.tiles_n, a.nphase * a.splitk);
+  if (precision == FCD_PREC_BF16)
+    hipLaunchKernelGGL((conv_gather_kernel<BM, BN, WM, WN, true>), grid, dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL((conv_gather_kernel<BM, BN, WM, WN, false>), grid, dim3(256), 0, st, a);
+  return fcd_check_launch("conv_gather");
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_wgrad(const WgradArgs& a, int precision, hipStream_t st) {
+  dim3 grid(a.tiles_m * a.tiles_n, a.splitk);
+  if (precision == FCD_PREC_BF16)
+    hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN, true>), grid, dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN, false>), grid, dim3(256), 0, st, a);
+  return fcd_check_launch("conv_wgrad");
+}
+
+int validate_conv(const FcdConvDesc* d) {
+  FCD_REQUIRE(d != nullptr, "conv: null descriptor");
+  FCD_REQUIRE(d->N > 0 && d->IH > 0 && d->IW > 0 && d->GH > 0 && d->GW > 0 && d->OH > 0 && d->OW > 0,
+              "conv: non-positive extent");
+  FCD_REQUIRE(d->Cin > 0 && d->Cin % 4 == 0, "conv: Cin=%d must be a positive multiple of 4", d->Cin);
+  FCD_REQUIRE(d->Cout > 0 && d->CoutP >= d->Cout, "conv: Cout=%d CoutP=%d", d->Cout, d->CoutP);
+  FCD_REQUIRE(d->KH > 0 && d->KW > 0, "conv: taps");
+  FCD_REQUIRE(d->istride >= 1 && d->ostride >= 1, "conv: strides");
+  FCD_REQUIRE(d->nphase >= 1 && d->nphase <= 4, "conv: nphase=%d", d->nphase);
+  FCD_REQUIRE(d->splitk >= 1 && d->splitk <= 1024, "conv: splitk=%d", d->splitk);
+  FCD_REQUIRE(d->precision == FCD_PREC_F32 || d->precision == FCD_PREC_BF16, "conv: precision");
+  for (int ph = 0; ph < d->nphase; ++ph) {
+    const long oh = (long)(d->GH - 1) * d->ostride + d->ooff_h[ph];
+    const long ow = (long)(d->GW - 1) * d->ostride + d->ooff_w[ph];
+    FCD_REQUIRE(d->ooff_h[ph] >= 0 && d->ooff_w[ph] >= 0 && oh < d->OH && ow < d->OW,
+                "conv: phase %d writes outside the %dx%d output", ph, d->OH, d->OW);
+  }
+  FCD_REQUIRE((long)d->N * d->GH * d->GW < (1l << 31), "conv: too many output pixels");
+  return FCD_OK;
+}
+
+void fill_gather_args(const FcdConvDesc* d, GatherArgs& a) {
+  a.N = d->N; a.IH = d->IH; a.IW = d->IW; a.Cin = d->Cin; a.GH = d->GH; a.GW = d->GW;
+  a.OH = d->OH; a.OW = d->OW; a.Cout = d->Cout; a.CoutP = d->CoutP; a.KH = d->KH; a.KW = d->KW;
+  a.K = d->KH * d->KW * d->Cin;
+  a.istride = d->istride; a.ostride = d->ostride; a.nphase = d->nphase; a.splitk = d->splitk;
+  for (int i = 0; i < 4; ++i) {
+    a.pad_h[i] = d->pad_h[i]; a.pad_w[i] = d->pad_w[i];
+    a.ooff_h[i] = d->ooff_h[i]; a.ooff_w[i] = d->ooff_w[i];
+  }
+  a.M = d->N * d->GH * d->GW;
+  const int bk = d->precision == FCD_PREC_BF16 ? 64 : 32;
+  a.ktiles = fcd_cdiv(a.K, bk);
+  a.ktiles_per_split = fcd_cdiv(a.ktiles, d->splitk);
+  a.w_phase_stride = (long)d->Cout * a.K;
+  a.act_slope = d->act_slope; a.mask_slope = d->mask_slope;
+}
+
+}  // namespace
+
+extern "C" size_t fcd_conv_workspace_bytes(const FcdConvDesc* d) {
+  if (!d || d->splitk <= 1) return 0;
+  return (size_t)d->nphase * d->splitk * d->N * d->GH * d->GW * d->CoutP * sizeof(float);
+}
+
+extern "C" int fcd_conv_gather(const FcdConvDesc* d, const float* in, const float* w_packed,
+                               const float* bias, const float* mask_src, const float* residual,
+                               float* out, void* workspace, size_t workspace_bytes, void* stream) {
+  int rc = validate_conv(d);
+  if (rc) return rc;
+  FCD_REQUIRE(in && w_packed && out, "conv: null tensor");
+  FCD_REQUIRE(((uintptr_t)in % 16) == 0 && ((uintptr_t)w_packed % 16) == 0, "conv: operands must be 16-byte aligned");
+  const size_t need = fcd_conv_workspace_bytes(d);
+  if (need > 0 && (workspace == nullptr || workspace_bytes < need)) {
+    fcd_set_error("conv: workspace %zu < %zu bytes", workspace_bytes, need);
+    return FCD_EWORKSPACE;
+  }
+  GatherArgs a;
+  fill_gather_args(d, a);
+  a.in = in; a.w = w_packed; a.bias = bias; a.mask = mask_src; a.res = residual; a.out = out;
+  a.slab = (float*)workspace;
+  hipStream_t st = fcd_stream(stream);
+  // tile shape by problem shape
+  if (d->Cout <= 32) {
+    a.tiles_m = fcd_cdiv(a.M, 128); a.tiles_n = fcd_cdiv(d->Cout, 32);
+    rc = launch_gather<128, 32, 4, 1>(a, d->precision, st);
+  } else if (d->Cout <= 64) {
+    a.tiles_m = fcd_cdiv(a.M, 128); a.tiles_n = fcd_cdiv(d->Cout, 64);
+    rc = launch_gather<128, 64, 2, 2>(a, d->precision, st);
+  } else if (a.M <= 64) {
+    a.tiles_m = fcd_cdiv(a.M, 64); a.tiles_n = fcd_cdiv(d->Cout, 128);
+    rc = launch_gather<64, 128, 2, 2>(a, d->precision, st);
+  } else {
+    a.tiles_m = fcd_cdiv(a.M, 128); a.tiles_n = fcd_cdiv(d->Cout, 128);
+    rc = launch_gather<128, 128, 2, 2>(a, d->precision, st);
+  }
+  if (rc) return rc;
+  if (d->splitk > 1) {
+    const long total = (long)a.nphase * a.M * a.CoutP;
+    const int blocks = (int)std::min<long>(fcd_cdiv(total, 256), 4096);
+    hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, a);
+    rc = fcd_check_launch("conv_splitk_reduce");
+  }
+  return rc;
+}
+
+static int validate_wgrad(const FcdWgradDesc* d) {
+  FCD_REQUIRE(d != nullptr, "wgrad: null descriptor");
+  FCD_REQUIRE(d->N > 0 && d->GH > 0 && d->GW > 0 && d->BH > 0 && d->BW > 0, "wgrad: extents");
+  FCD_REQUIRE(d->O > 0 && d->OP >= d->O && d->OP % 4 == 0, "wgrad: O=%d OP=%d", d->O, d->OP);
+  FCD_REQUIRE(d->I > 0 && d->IP >= d->I && d->IP % 4 == 0, "wgrad: I=%d IP=%d", d->I, d->IP);
+  FCD_REQUIRE(d->KH > 0 && d->KW > 0 && d->stride >= 1 && d->pad >= 0, "wgrad: kernel");
+  FCD_REQUIRE(d->splitk >= 1 && d->splitk <= 4096, "wgrad: splitk=%d", d->splitk);
+  FCD_REQUIRE((long)d->N * d->GH * d->GW < (1l << 31), "wgrad: too many pixels");
+  return FCD_OK;
+}
+
+extern "C" size_t fcd_wgrad_workspace_bytes(const FcdWgradDesc* d) {
+  if (!d) return 0;
+  return (size_t)d->splitk * d->O * d->KH * d->KW * d->IP * sizeof(float);
+}
+
+extern "C" int fcd_conv_wgrad(const FcdWgradDesc* d, const float* gsmall, const float* xbig, float* dw,
+                              void* workspace, size_t workspace_bytes, void* stream) {
+  int rc = validate_wgrad(d);
+  if (rc) return rc;
+  FCD_REQUIRE(gsmall && xbig && dw, "wgrad: null tensor");
+  const size_t need = fcd_wgrad_workspace_bytes(d);
+  if (workspace == nullptr || workspace_bytes < need) {
+    fcd_set_error("wgrad: workspace %zu < %zu bytes", workspace_bytes, need);
+    return FCD_EWORKSPACE;
+  }
+  WgradArgs a;
+  a.gs = gsmall; a.xb = xbig; a.slab = (float*)workspace; a.dw = dw;
+  a.N = d->N; a.GH = d->GH; a.GW = d->GW; a.O = d->O; a.OP = d->OP; a.BH = d->BH; a.BW = d->BW;
+  a.I = d->I; a.IP = d->IP; a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
+  a.P = d->N * d->GH * d->GW;
+  a.ND = d->KH * d->KW * d->IP;
+  a.splitk = d->splitk;
+  a.ktiles = fcd_cdiv(a.P, 32);
+  a.ktiles_per_split = fcd_cdiv(a.ktiles, d->splitk);
+  a.accumulate = d->accumulate;
+  hipStream_t st = fcd_stream(stream);
+  if (d->O <= 32) {
+    a.tiles_m = fcd_cdiv(d->O, 32); a.tiles_n = fcd_cdiv(a.ND, 128);
+    rc = launch_wgrad<32, 128, 1, 4>(a, d->precision, st);
+  } else if (d->O <= 64) {
+    a.tiles_m = fcd_cdiv(d->O, 64); a.tiles_n = fcd_cdiv(a.ND, 128);
+    rc = launch_wgrad<64, 128, 2, 2>(a, d->precision, st);
+  } else {
+    a.tiles_m = fcd_cdiv(d->O, 128); a.tiles_n = fcd_cdiv(a.ND, 128);
+    rc = launch_wgrad<128, 128, 2, 2>(a, d->precision, st);
+  }
+  if (rc) return rc;
+  const long total = (long)d->O * d->I * d->KH * d->KW;
+  const int blocks = (int)std::min<long>(fcd_cdiv(total, 256), 4096);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, a);
+  return fcd_check_launch("wgrad_reduce");
+}
+
+extern "C" int fcd_pack_weight_fwd(const float* w, float* packed, int O, int I, int IP, int KH, int KW,
+                                   void* stream) {
+  FCD_REQUIRE(w && packed && O > 0 && I > 0 && IP >= I && IP % 4 == 0 && KH > 0 && KW > 0, "pack_fwd: bad arguments");
+  const long total = (long)O * KH * KW * IP;
+  const int blocks = (int)std::min<long>(fcd_cdiv(total, 256), 4096);
+  hipLaunchKernelGGL(pack_fwd_kernel, dim3(blocks), dim3(256), 0, fcd_stream(stream), w, packed, O, I, IP, KH * KW);
+  return fcd_check_launch("pack_fwd");
+}
+
+extern "C" int fcd_pack_weight_adj(const float* w, float* packed, int O, int OP, int I, int KH, int KW,
+                                   int stride, void* stream) {
+  FCD_REQUIRE(w && packed && O > 0 && I > 0 && OP >= O && OP % 4 == 0, "pack_adj: bad arguments");
+  FCD_REQUIRE(stride == 1 || (stride == 2 && KH == 4 && KW == 4), "pack_adj: stride %d with %dx%d taps unsupported", stride, KH, KW);
+  const int TH = stride == 1 ? KH : 2, TW = stride == 1 ? KW : 2, nph = stride == 1 ? 1 : 4;
+  const long total = (long)nph * I * TH * TW * OP;
+  const int blocks = (int)std::min<long>(fcd_cdiv(total, 256), 4096);
+  hipLaunchKernelGGL(pack_adj_kernel, dim3(blocks), dim3(256), 0, fcd_stream(stream), w, packed, O, OP, I, KH, KW, stride);
+  return fcd_check_launch("pack_adj");
+}

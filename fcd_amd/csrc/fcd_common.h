@@ -1,0 +1,64 @@
+// Internal helpers shared by the gfx950 kernels of libfcd_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include "../../include/fcd_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+void fcd_set_error(const char* fmt, ...);
+
+#define FCD_REQUIRE(cond, ...)            \
+  do {                                    \
+    if (!(cond)) {                        \
+      fcd_set_error(__VA_ARGS__);         \
+      return FCD_EINVAL;                  \
+    }                                     \
+  } while (0)
+
+// Launch errors surface as a positive hipError_t.
+static inline int fcd_check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    fcd_set_error("%s: %s", what, hipGetErrorString(e));
+    return (int)e;
+  }
+  return FCD_OK;
+}
+
+static inline hipStream_t fcd_stream(void* s) { return (hipStream_t)s; }
+
+static inline int fcd_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// 64-lane wavefront sum (gfx950: wave = 64).
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Block sum for blockDim.x = 256 (4 waves); result valid in every thread.
+__device__ __forceinline__ float block_sum_256(float v, float* smem4) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) smem4[w] = v;
+  __syncthreads();
+  return smem4[0] + smem4[1] + smem4[2] + smem4[3];
+}
+__device__ __forceinline__ double block_sum_256_d(double v, double* smem4) {
+  v = wave_sum_d(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) smem4[w] = v;
+  __syncthreads();
+  return smem4[0] + smem4[1] + smem4[2] + smem4[3];
+}

@@ -1,0 +1,378 @@
+// InstanceNorm2d (+activation, +residual) forward/backward on NHWC fp32, and the column
+// reductions they share with the bias gradients.  All of these are HBM-bound: every tensor
+// is touched with 16-byte accesses along the channel axis, partial sums are combined in
+// double precision in a fixed order (bitwise reproducible, no atomics).
+#include "fcd_common.h"
+
+namespace {
+
+constexpr int MODE_STATS = 0;  // a0 = z, a1 = z*z
+constexpr int MODE_BWD = 1;    // g1 = gy*act'(y): a0 = g1, a1 = g1*xhat
+constexpr int MODE_SUM = 2;    // a0 = x
+
+struct ColPlan {
+  int c4;       // float4 columns
+  int c4b;      // float4 columns per block (<= 256)
+  int cblocks;  // column blocks (grid.z)
+  int rows;     // pixel rows handled concurrently by one block
+  int chunks;   // pixel chunks per image
+  int chunk_len;
+};
+
+// Shared by the workspace query and the launch.
+ColPlan col_plan(int N, long HW, int C) {
+  ColPlan p;
+  p.c4 = C / 4;
+  p.c4b = p.c4 < 256 ? p.c4 : 256;
+  p.cblocks = (p.c4 + 255) / 256;
+  p.rows = 256 / p.c4b;
+  if (p.rows < 1) p.rows = 1;
+  long want = 2048 / (N > 0 ? N : 1);
+  if (want < 1) want = 1;
+  long maxc = (HW + p.rows - 1) / p.rows;   // at least one row per thread
+  long chunks = want < maxc ? want : maxc;
+  if (chunks < 1) chunks = 1;
+  p.chunk_len = (int)((HW + chunks - 1) / chunks);
+  p.chunks = (int)((HW + p.chunk_len - 1) / p.chunk_len);
+  return p;
+}
+
+// partial[n][chunk][c][2] (double)
+template <int MODE>
+__global__ __launch_bounds__(256) void col_partial_kernel(const float* __restrict__ x0, const float* __restrict__ x1,
+                                                          const float* __restrict__ x2, const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd, double* __restrict__ partial,
+                                                          long HW, int C, ColPlan pl, float act_slope) {
+  extern __shared__ double sm[];   // [rows][C][2]
+  const int n = blockIdx.y, chunk = blockIdx.x;
+  const int c4b = pl.c4b, CB = c4b * 4;
+  const int cbase = blockIdx.z * 1024;
+  const int tx = threadIdx.x % c4b, ty = threadIdx.x / c4b;
+  const bool active = ty < pl.rows && cbase / 4 + tx < pl.c4;
+  float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+  if (active) {
+    const long p0 = (long)chunk * pl.chunk_len;
+    const long p1 = min(HW, p0 + pl.chunk_len);
+    float mu[4] = {0, 0, 0, 0}, rs[4] = {0, 0, 0, 0};
+    if (MODE == MODE_BWD) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        mu[e] = mean[(long)n * C + cbase + tx * 4 + e];
+        rs[e] = rstd[(long)n * C + cbase + tx * 4 + e];
+      }
+    }
+    for (long px = p0 + ty; px < p1; px += pl.rows) {
+      const long off = ((long)n * HW + px) * C + cbase + tx * 4;
+      const float4 a = *reinterpret_cast<const float4*>(x0 + off);
+      const float av[4] = {a.x, a.y, a.z, a.w};
+      if (MODE == MODE_STATS) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          s0[e] += av[e];
+          s1[e] += av[e] * av[e];
+        }
+      } else if (MODE == MODE_SUM) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s0[e] += av[e];
+      } else {
+        const float4 y = *reinterpret_cast<const float4*>(x1 + off);
+        const float4 z = *reinterpret_cast<const float4*>(x2 + off);
+        const float yv[4] = {y.x, y.y, y.z, y.w}, zv[4] = {z.x, z.y, z.z, z.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float g1 = av[e] * (yv[e] > 0.f ? 1.f : act_slope);
+          s0[e] += g1;
+          s1[e] += g1 * ((zv[e] - mu[e]) * rs[e]);
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      sm[((long)ty * CB + tx * 4 + e) * 2 + 0] = (double)s0[e];
+      sm[((long)ty * CB + tx * 4 + e) * 2 + 1] = (double)s1[e];
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < CB && cbase + c < C; c += 256) {
+    double t0 = 0.0, t1 = 0.0;
+    for (int r = 0; r < pl.rows; ++r) {
+      t0 += sm[((long)r * CB + c) * 2 + 0];
+      t1 += sm[((long)r * CB + c) * 2 + 1];
+    }
+    double* dst = partial + (((long)n * pl.chunks + chunk) * C + cbase + c) * 2;
+    dst[0] = t0;
+    dst[1] = t1;
+  }
+}
+
+__global__ __launch_bounds__(256) void stats_finalize_kernel(const double* __restrict__ partial, float* __restrict__ mean,
+                                                             float* __restrict__ rstd, float* __restrict__ var_unb,
+                                                             int N, long HW, int C, int chunks, float eps) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)N * C) return;
+  const int n = (int)(idx / C), c = (int)(idx % C);
+  double s = 0.0, ss = 0.0;
+  for (int k = 0; k < chunks; ++k) {
+    const double* src = partial + (((long)n * chunks + k) * C + c) * 2;
+    s += src[0];
+    ss += src[1];
+  }
+  const double m = s / (double)HW;
+  double var = ss / (double)HW - m * m;
+  if (var < 0.0) var = 0.0;
+  mean[idx] = (float)m;
+  rstd[idx] = (float)(1.0 / sqrt(var + (double)eps));
+  if (var_unb) var_unb[idx] = (float)(HW > 1 ? var * ((double)HW / (double)(HW - 1)) : var);
+}
+
+// s12[n][c][2] floats from the partials
+__global__ __launch_bounds__(256) void bwd_finalize_kernel(const double* __restrict__ partial, float* __restrict__ s12,
+                                                           int N, int C, int chunks) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)N * C) return;
+  const int n = (int)(idx / C), c = (int)(idx % C);
+  double s = 0.0, ss = 0.0;
+  for (int k = 0; k < chunks; ++k) {
+    const double* src = partial + (((long)n * chunks + k) * C + c) * 2;
+    s += src[0];
+    ss += src[1];
+  }
+  s12[idx * 2 + 0] = (float)s;
+  s12[idx * 2 + 1] = (float)ss;
+}
+
+__global__ __launch_bounds__(256) void affine_grad_kernel(const float* __restrict__ s12, float* __restrict__ dgamma,
+                                                          float* __restrict__ dbeta, int N, int C, int accumulate) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double a = 0.0, b = 0.0;
+  for (int n = 0; n < N; ++n) {
+    b += (double)s12[((long)n * C + c) * 2 + 0];
+    a += (double)s12[((long)n * C + c) * 2 + 1];
+  }
+  if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)a : (float)a;
+  if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)b : (float)b;
+}
+
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const double* __restrict__ partial, float* __restrict__ out,
+                                                              int C, int chunks, int accumulate) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int k = 0; k < chunks; ++k) s += partial[((long)k * C + c) * 2];
+  out[c] = accumulate ? out[c] + (float)s : (float)s;
+}
+
+__global__ __launch_bounds__(256) void in_apply_kernel(const float* __restrict__ z, const float* __restrict__ mean,
+                                                       const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, const float* __restrict__ res,
+                                                       float* __restrict__ y, long HW, int C, long total4, float act_slope) {
+  const int c4 = C / 4;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total4; idx += (long)gridDim.x * 256) {
+    const int cc = (int)(idx % c4) * 4;
+    const long n = idx / ((long)HW * c4);
+    const float4 zv = *reinterpret_cast<const float4*>(z + idx * 4);
+    const float4 mu = *reinterpret_cast<const float4*>(mean + n * C + cc);
+    const float4 rs = *reinterpret_cast<const float4*>(rstd + n * C + cc);
+    const float4 ga = *reinterpret_cast<const float4*>(gamma + cc);
+    const float4 be = *reinterpret_cast<const float4*>(beta + cc);
+    float4 o;
+    o.x = (zv.x - mu.x) * rs.x * ga.x + be.x;
+    o.y = (zv.y - mu.y) * rs.y * ga.y + be.y;
+    o.z = (zv.z - mu.z) * rs.z * ga.z + be.z;
+    o.w = (zv.w - mu.w) * rs.w * ga.w + be.w;
+    o.x = o.x > 0.f ? o.x : o.x * act_slope;
+    o.y = o.y > 0.f ? o.y : o.y * act_slope;
+    o.z = o.z > 0.f ? o.z : o.z * act_slope;
+    o.w = o.w > 0.f ? o.w : o.w * act_slope;
+    if (res) {
+      const float4 r = *reinterpret_cast<const float4*>(res + idx * 4);
+      o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+    }
+    *reinterpret_cast<float4*>(y + idx * 4) = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void in_bwd_apply_kernel(const float* __restrict__ gy, const float* __restrict__ y,
+                                                           const float* __restrict__ z, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                           const float* __restrict__ s12, float* __restrict__ dz, long HW,
+                                                           int C, long total4, float act_slope, int use_running) {
+  const int c4 = C / 4;
+  const float inv_hw = 1.f / (float)HW;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total4; idx += (long)gridDim.x * 256) {
+    const int cc = (int)(idx % c4) * 4;
+    const long n = idx / ((long)HW * c4);
+    const float4 g = *reinterpret_cast<const float4*>(gy + idx * 4);
+    const float4 yv = *reinterpret_cast<const float4*>(y + idx * 4);
+    const float4 zv = *reinterpret_cast<const float4*>(z + idx * 4);
+    const float gv[4] = {g.x, g.y, g.z, g.w}, yy[4] = {yv.x, yv.y, yv.z, yv.w}, zz[4] = {zv.x, zv.y, zv.z, zv.w};
+    float o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const long nc = n * C + cc + e;
+      const float g1 = gv[e] * (yy[e] > 0.f ? 1.f : act_slope);
+      const float rs = rstd[nc];
+      if (use_running) {
+        o[e] = gamma[cc + e] * rs * g1;
+      } else {
+        const float xh = (zz[e] - mean[nc]) * rs;
+        o[e] = gamma[cc + e] * rs * (g1 - s12[nc * 2] * inv_hw - xh * (s12[nc * 2 + 1] * inv_hw));
+      }
+    }
+    *reinterpret_cast<float4*>(dz + idx * 4) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+__global__ __launch_bounds__(256) void stats_from_running_kernel(const float* __restrict__ rm, const float* __restrict__ rv,
+                                                                 float* __restrict__ mean, float* __restrict__ rstd, int N,
+                                                                 int C, float eps) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)N * C) return;
+  const int c = (int)(idx % C);
+  mean[idx] = rm[c];
+  rstd[idx] = 1.f / sqrtf(rv[c] + eps);
+}
+
+__global__ __launch_bounds__(256) void update_running_kernel(float* __restrict__ rm, float* __restrict__ rv,
+                                                             const float* __restrict__ mean, const float* __restrict__ varu,
+                                                             int N, int C, float momentum) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float sm = 0.f, sv = 0.f;
+  for (int n = 0; n < N; ++n) {
+    sm += mean[(long)n * C + c];
+    sv += varu[(long)n * C + c];
+  }
+  rm[c] = (1.f - momentum) * rm[c] + momentum * (sm / (float)N);
+  rv[c] = (1.f - momentum) * rv[c] + momentum * (sv / (float)N);
+}
+
+int check_nhwc(const char* what, int N, long HW, int C) {
+  FCD_REQUIRE(N > 0 && HW > 0 && C > 0 && C % 4 == 0, "%s: N=%d HW=%ld C=%d (C must be a multiple of 4)", what, N, HW, C);
+  return FCD_OK;
+}
+
+size_t partial_bytes(int N, long HW, int C) {
+  ColPlan pl = col_plan(N, HW, C);
+  return (size_t)N * pl.chunks * C * 2 * sizeof(double);
+}
+
+}  // namespace
+
+extern "C" size_t fcd_instnorm_workspace_bytes(int N, int HW, int C) {
+  if (N <= 0 || HW <= 0 || C <= 0 || C % 4) return 0;
+  return partial_bytes(N, HW, C) + (size_t)N * C * 2 * sizeof(float) + 64;
+}
+
+extern "C" int fcd_instnorm_stats(const float* z, float* mean, float* rstd, float* var_unbiased, int N, int HW,
+                                  int C, float eps, void* workspace, size_t workspace_bytes, void* stream) {
+  int rc = check_nhwc("instnorm_stats", N, HW, C);
+  if (rc) return rc;
+  FCD_REQUIRE(z && mean && rstd, "instnorm_stats: null tensor");
+  if (!workspace || workspace_bytes < partial_bytes(N, HW, C)) {
+    fcd_set_error("instnorm_stats: workspace too small");
+    return FCD_EWORKSPACE;
+  }
+  ColPlan pl = col_plan(N, HW, C);
+  hipStream_t st = fcd_stream(stream);
+  const size_t shm = (size_t)pl.rows * pl.c4b * 4 * 2 * sizeof(double);
+  hipLaunchKernelGGL((col_partial_kernel<MODE_STATS>), dim3(pl.chunks, N, pl.cblocks), dim3(256), shm, st, z, nullptr, nullptr,
+                     nullptr, nullptr, (double*)workspace, (long)HW, C, pl, 0.f);
+  rc = fcd_check_launch("instnorm_stats/partial");
+  if (rc) return rc;
+  hipLaunchKernelGGL(stats_finalize_kernel, dim3(fcd_cdiv((long)N * C, 256)), dim3(256), 0, st,
+                     (const double*)workspace, mean, rstd, var_unbiased, N, (long)HW, C, pl.chunks, eps);
+  return fcd_check_launch("instnorm_stats/finalize");
+}
+
+extern "C" int fcd_instnorm_stats_from_running(const float* running_mean, const float* running_var, float* mean,
+                                               float* rstd, int N, int C, float eps, void* stream) {
+  FCD_REQUIRE(running_mean && running_var && mean && rstd && N > 0 && C > 0, "stats_from_running: bad arguments");
+  hipLaunchKernelGGL(stats_from_running_kernel, dim3(fcd_cdiv((long)N * C, 256)), dim3(256), 0, fcd_stream(stream),
+                     running_mean, running_var, mean, rstd, N, C, eps);
+  return fcd_check_launch("stats_from_running");
+}
+
+extern "C" int fcd_instnorm_update_running(float* running_mean, float* running_var, const float* mean,
+                                           const float* var_unbiased, int N, int C, float momentum, void* stream) {
+  FCD_REQUIRE(running_mean && running_var && mean && var_unbiased && N > 0 && C > 0, "update_running: bad arguments");
+  hipLaunchKernelGGL(update_running_kernel, dim3(fcd_cdiv(C, 256)), dim3(256), 0, fcd_stream(stream), running_mean,
+                     running_var, mean, var_unbiased, N, C, momentum);
+  return fcd_check_launch("update_running");
+}
+
+extern "C" int fcd_instnorm_apply(const float* z, const float* mean, const float* rstd, const float* gamma,
+                                  const float* beta, const float* residual, float* y, int N, int HW, int C,
+                                  float act_slope, void* stream) {
+  int rc = check_nhwc("instnorm_apply", N, HW, C);
+  if (rc) return rc;
+  FCD_REQUIRE(z && mean && rstd && gamma && beta && y, "instnorm_apply: null tensor");
+  const long total4 = (long)N * HW * (C / 4);
+  const int blocks = (int)std::min<long>(fcd_cdiv(total4, 256), 8192);
+  hipLaunchKernelGGL(in_apply_kernel, dim3(blocks), dim3(256), 0, fcd_stream(stream), z, mean, rstd, gamma, beta,
+                     residual, y, (long)HW, C, total4, act_slope);
+  return fcd_check_launch("instnorm_apply");
+}
+
+extern "C" int fcd_instnorm_bwd(const float* gy, const float* y, const float* z, const float* mean, const float* rstd,
+                                const float* gamma, float* dz, float* dgamma, float* dbeta, int accumulate, int N,
+                                int HW, int C, float act_slope, int use_running, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+  int rc = check_nhwc("instnorm_bwd", N, HW, C);
+  if (rc) return rc;
+  FCD_REQUIRE(gy && y && z && mean && rstd && gamma && dz, "instnorm_bwd: null tensor");
+  const size_t pb = partial_bytes(N, HW, C);
+  if (!workspace || workspace_bytes < pb + (size_t)N * C * 2 * sizeof(float)) {
+    fcd_set_error("instnorm_bwd: workspace too small");
+    return FCD_EWORKSPACE;
+  }
+  ColPlan pl = col_plan(N, HW, C);
+  hipStream_t st = fcd_stream(stream);
+  double* partial = (double*)workspace;
+  float* s12 = (float*)((char*)workspace + pb);
+  const size_t shm = (size_t)pl.rows * pl.c4b * 4 * 2 * sizeof(double);
+  hipLaunchKernelGGL((col_partial_kernel<MODE_BWD>), dim3(pl.chunks, N, pl.cblocks), dim3(256), shm, st, gy, y, z, mean, rstd,
+                     partial, (long)HW, C, pl, act_slope);
+  rc = fcd_check_launch("instnorm_bwd/partial");
+  if (rc) return rc;
+  hipLaunchKernelGGL(bwd_finalize_kernel, dim3(fcd_cdiv((long)N * C, 256)), dim3(256), 0, st, partial, s12, N, C, pl.chunks);
+  rc = fcd_check_launch("instnorm_bwd/finalize");
+  if (rc) return rc;
+  if (dgamma || dbeta) {
+    hipLaunchKernelGGL(affine_grad_kernel, dim3(fcd_cdiv(C, 256)), dim3(256), 0, st, s12, dgamma, dbeta, N, C, accumulate);
+    rc = fcd_check_launch("instnorm_bwd/affine");
+    if (rc) return rc;
+  }
+  const long total4 = (long)N * HW * (C / 4);
+  const int blocks = (int)std::min<long>(fcd_cdiv(total4, 256), 8192);
+  hipLaunchKernelGGL(in_bwd_apply_kernel, dim3(blocks), dim3(256), 0, st, gy, y, z, mean, rstd, gamma, s12, dz, (long)HW,
+                     C, total4, act_slope, use_running);
+  return fcd_check_launch("instnorm_bwd/apply");
+}
+
+extern "C" size_t fcd_colsum_workspace_bytes(size_t rows, int C) {
+  if (rows == 0 || C <= 0 || C % 4) return 0;
+  return partial_bytes(1, (long)rows, C) + 64;
+}
+
+extern "C" int fcd_colsum(const float* x, float* out, int accumulate, size_t rows, int C, void* workspace,
+                          size_t workspace_bytes, void* stream) {
+  int rc = check_nhwc("colsum", 1, (long)rows, C);
+  if (rc) return rc;
+  FCD_REQUIRE(x && out, "colsum: null tensor");
+  if (!workspace || workspace_bytes < partial_bytes(1, (long)rows, C)) {
+    fcd_set_error("colsum: workspace too small");
+    return FCD_EWORKSPACE;
+  }
+  ColPlan pl = col_plan(1, (long)rows, C);
+  hipStream_t st = fcd_stream(stream);
+  const size_t shm = (size_t)pl.rows * pl.c4b * 4 * 2 * sizeof(double);
+  hipLaunchKernelGGL((col_partial_kernel<MODE_SUM>), dim3(pl.chunks, 1, pl.cblocks), dim3(256), shm, st, x, nullptr, nullptr, nullptr,
+                     nullptr, (double*)workspace, (long)rows, C, pl, 0.f);
+  rc = fcd_check_launch("colsum/partial");
+  if (rc) return rc;
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(fcd_cdiv(C, 256)), dim3(256), 0, st, (const double*)workspace, out, C,
+                     pl.chunks, accumulate);
+  return fcd_check_launch("colsum/finalize");
+}

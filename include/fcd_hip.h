@@ -1,0 +1,226 @@
+/*
+ * fcd_hip.h -- C ABI of libfcd_hip.so: the MI355X (gfx950) kernels behind the
+ * FCD Fixed-Point GAN hot path.
+ *
+ * The reference (denix56/fcd) has no FFI for this path: its boundary is the
+ * Python nn.Module / solver API (models/fixed_point_gan.py, fcd_solver.py) and
+ * every op below is a stock torch.nn / torch op there.  Each entry point cites
+ * the reference line whose arithmetic it replaces.  The Python side
+ * (fcd_amd/) binds these with ctypes and keeps the reference's module and
+ * solver signatures.
+ *
+ * Conventions
+ *  - all pointers are DEVICE pointers unless named host_*; the library borrows
+ *    them for the duration of the call and allocates nothing;
+ *  - activations inside the library are NHWC fp32 with the channel count padded
+ *    to a multiple of 4 ("physical" channels, pad lanes hold zeros); the
+ *    module boundary is NCHW fp32 like the reference;
+ *  - every call is asynchronous on `stream` (a hipStream_t passed as void*);
+ *  - return value: 0 = ok, otherwise a negative FCD_E* code or a positive
+ *    hipError_t; fcd_last_error() gives a message for the calling thread;
+ *  - scratch comes from the caller: query *_workspace_bytes first.
+ */
+#ifndef FCD_HIP_H
+#define FCD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FCD_ABI_VERSION 1
+
+#define FCD_OK 0
+#define FCD_EINVAL (-1)   /* bad descriptor / shape / alignment            */
+#define FCD_EWORKSPACE (-2) /* workspace too small                          */
+#define FCD_ENODEVICE (-3)  /* no HIP device / wrong architecture           */
+
+/* precision of the MFMA contraction */
+#define FCD_PREC_F32 0   /* v_mfma_f32_32x32x2_f32: exact fp32 fma chain     */
+#define FCD_PREC_BF16 1  /* operands rounded to bf16 at LDS staging, fp32 accumulate */
+
+const char* fcd_last_error(void);
+int fcd_abi_version(void);
+/* Checks that `device` is a gfx950 part and makes it current. */
+int fcd_init(int device);
+
+/* ------------------------------------------------------------------------- *
+ * Implicit-GEMM convolution, "gather" form.
+ *   out[n, a*ostride+ooff_h[ph], b*ostride+ooff_w[ph], co] =
+ *     epilogue( sum_{th,tw,ci} in[n, a*istride - pad_h[ph] + th,
+ *                                    b*istride - pad_w[ph] + tw, ci]
+ *                              * w[ph][co][th][tw][ci] )
+ * for (a, b) in GH x GW and every phase ph < nphase.  One phase with
+ * ostride 1 is an ordinary nn.Conv2d (fixed_point_gan.py:27,30,45,52,68,111,
+ * 134,135); four 2x2-tap phases with ostride 2 are nn.ConvTranspose2d(k4,s2,p1)
+ * (fixed_point_gan.py:63) and equally the data gradient of Conv2d(k4,s2,p1);
+ * one phase with flipped taps is the data gradient of a stride-1 conv.
+ * epilogue(v): v += bias[co]; v = v > 0 ? v : v*act_slope (act_slope 1 = none);
+ *              v *= (mask_src[o] > 0 ? 1 : mask_slope) if mask_src;
+ *              v += residual[o] if residual.
+ * ------------------------------------------------------------------------- */
+typedef struct FcdConvDesc {
+  int32_t N, IH, IW, Cin;        /* input NHWC, Cin physical (multiple of 4)     */
+  int32_t GH, GW;                /* output pixel grid per phase                  */
+  int32_t OH, OW, Cout, CoutP;   /* output NHWC, CoutP physical channel stride   */
+  int32_t KH, KW;                /* taps per phase                               */
+  int32_t istride, ostride;
+  int32_t nphase;
+  int32_t pad_h[4], pad_w[4];
+  int32_t ooff_h[4], ooff_w[4];
+  int32_t splitk;                /* >= 1; partial sums go through the workspace  */
+  int32_t precision;             /* FCD_PREC_*                                   */
+  float act_slope;               /* LeakyReLU slope of the epilogue, 1 = identity */
+  float mask_slope;              /* slope used with mask_src                     */
+} FcdConvDesc;
+
+size_t fcd_conv_workspace_bytes(const FcdConvDesc* d);
+int fcd_conv_gather(const FcdConvDesc* d, const float* in, const float* w_packed,
+                    const float* bias, const float* mask_src, const float* residual,
+                    float* out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Weight gradient of the same convolution family:
+ *   dw[o][i][kh][kw] (+)= sum_{n,a,b} gsmall[n,a,b,o] *
+ *                          xbig[n, a*stride - pad + kh, b*stride - pad + kw, i]
+ * (torch's conv2d weight gradient; for ConvTranspose2d the roles of input and
+ * output gradient swap).  dw is in the PyTorch parameter layout [O][I][KH][KW]. */
+typedef struct FcdWgradDesc {
+  int32_t N, GH, GW, O, OP;      /* gsmall NHWC [N][GH][GW][OP], O logical       */
+  int32_t BH, BW, I, IP;         /* xbig   NHWC [N][BH][BW][IP], I logical       */
+  int32_t KH, KW, stride, pad;
+  int32_t splitk;
+  int32_t precision;
+  int32_t accumulate;            /* 1: dw += result                              */
+} FcdWgradDesc;
+
+size_t fcd_wgrad_workspace_bytes(const FcdWgradDesc* d);
+int fcd_conv_wgrad(const FcdWgradDesc* d, const float* gsmall, const float* xbig, float* dw,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
+/* Parameter layout [O][I][KH][KW]  ->  gather-form operand [O][KH][KW][IP]. */
+int fcd_pack_weight_fwd(const float* w, float* packed, int O, int I, int IP, int KH, int KW,
+                        void* stream);
+/* Parameter layout [O][I][KH][KW]  ->  adjoint operand [phase][I][TH][TW][OP]:
+ * stride 1: one phase, taps flipped; stride 2 (k4,p1): four phases of 2x2 taps. */
+int fcd_pack_weight_adj(const float* w, float* packed, int O, int OP, int I, int KH, int KW,
+                        int stride, void* stream);
+
+/* Small-Cout convolution heads of the Discriminator (conv1/conv2,
+ * fixed_point_gan.py:134-135; stride 1): direct dot products, no MFMA.
+ * w_packed = fcd_pack_weight_fwd layout [O][KH][KW][IP]; in NHWC [N][IH][IW][IP];
+ * out / gout NCHW [N][O][OH][OW] with OH = IH + 2*pad - KH + 1. */
+int fcd_head_fwd(const float* in, const float* w_packed, float* out, int N, int IH, int IW, int IP,
+                 int O, int KH, int KW, int pad, void* stream);
+/* din NHWC = (sum_{o,taps} gout[n,o,oh,ow] * w[o][kh][kw][i]) * lrelu'(mask_src) (+ din). */
+int fcd_head_dgrad(const float* gout, const float* w_packed, float* din, const float* mask_src,
+                   float mask_slope, int accumulate, int N, int IH, int IW, int IP, int O,
+                   int KH, int KW, int pad, void* stream);
+/* dw in the parameter layout [O][I][KH][KW] */
+int fcd_head_wgrad(const float* gout, const float* in, float* dw, int accumulate, int N, int IH,
+                   int IW, int I, int IP, int O, int KH, int KW, int pad, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * InstanceNorm2d(affine=True[, track_running_stats]) + activation, NHWC.
+ * (fixed_point_gan.py:28,31,46,53,64 with the ReLU of :29,47,54,65.)
+ * ------------------------------------------------------------------------- */
+/* mean[n][c], rstd[n][c] (biased variance, eps) over HW.  Workspace:
+ * fcd_instnorm_workspace_bytes(N, HW, C). */
+size_t fcd_instnorm_workspace_bytes(int N, int HW, int C);
+int fcd_instnorm_stats(const float* z, float* mean, float* rstd, float* var_unbiased, int N, int HW,
+                       int C, float eps, void* workspace, size_t workspace_bytes, void* stream);
+/* eval mode of a tracked norm: mean/rstd broadcast from the running buffers. */
+int fcd_instnorm_stats_from_running(const float* running_mean, const float* running_var,
+                                    float* mean, float* rstd, int N, int C, float eps, void* stream);
+/* running = (1-m)*running + m*batch-mean of (mean | unbiased var). */
+int fcd_instnorm_update_running(float* running_mean, float* running_var, const float* mean,
+                                const float* var_unbiased, int N, int C, float momentum,
+                                void* stream);
+/* y = act((z-mean)*rstd*gamma + beta) (+ residual); relu: act_slope 0, none: 1. */
+int fcd_instnorm_apply(const float* z, const float* mean, const float* rstd, const float* gamma,
+                       const float* beta, const float* residual, float* y, int N, int HW, int C,
+                       float act_slope, void* stream);
+/* Backward.  g1 = gy * act'(y).  Pass 1 reduces s1[n][c] = sum g1, s2 = sum g1*xhat;
+ * pass 2 writes dz = gamma*rstd*(g1 - s1/HW - xhat*s2/HW) (per-instance statistics) or
+ * dz = gamma*rstd*g1 (use_running: eval-mode tracked norm), and
+ * dgamma[c] (+)= sum_n s2, dbeta[c] (+)= sum_n s1. */
+int fcd_instnorm_bwd(const float* gy, const float* y, const float* z, const float* mean,
+                     const float* rstd, const float* gamma, float* dz, float* dgamma, float* dbeta,
+                     int accumulate, int N, int HW, int C, float act_slope, int use_running,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Generator prologue / epilogue (fixed_point_gan.py:73-75 and :78-82).
+ * ------------------------------------------------------------------------- */
+/* x NCHW [N][C][H][W], c [N][CD] -> NHWC [N][H][W][CP] = cat(x, tiled c), zero pad. */
+int fcd_g_prologue(const float* x, const float* c, float* out, int N, int C, int CD, int CP, int H,
+                   int W, void* stream);
+/* x_fake = tanh(delta + x) with invalid (x == -1) passthrough; delta NHWC [.][CP], out NCHW. */
+int fcd_g_epilogue_fwd(const float* delta, const float* x, float* x_fake, int N, int C, int CP,
+                       int H, int W, void* stream);
+/* gpre = gout * (1 - x_fake^2) * (x != -1): written NHWC [.][CP] (d delta, pad 0) and,
+ * if gx != NULL, NCHW into gx (accumulate_gx: +=): d x through the tanh(delta + x) skip. */
+int fcd_g_epilogue_bwd(const float* gout, const float* x, const float* x_fake, float* gdelta,
+                       float* gx, int accumulate_gx, int N, int C, int CP, int H, int W,
+                       void* stream);
+/* layout changes at the module boundary */
+int fcd_nchw_to_nhwc(const float* x, float* out, int N, int C, int CP, int H, int W, void* stream);
+/* out (+)= first C channels of the NHWC tensor */
+int fcd_nhwc_to_nchw(const float* x, float* out, int accumulate, int N, int C, int CP, int H, int W,
+                     void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Elementwise / reductions of the loss graph (fcd_solver.py).
+ * All scalar results are written to device memory (no host sync).
+ * ------------------------------------------------------------------------- */
+/* g * (y > 0 ? 1 : slope): LeakyReLU backward from the (in-place) output sign,
+ * fixed_point_gan.py:115. */
+int fcd_lrelu_bwd(const float* g, const float* y, float* out, size_t n, float slope, void* stream);
+/* out[c] (+)= sum over rows of x[rows][C]: bias gradients. */
+int fcd_colsum(const float* x, float* out, int accumulate, size_t rows, int C, void* workspace,
+               size_t workspace_bytes, void* stream);
+size_t fcd_colsum_workspace_bytes(size_t rows, int C);
+/* The three scalar reductions below are two-stage (fixed order, double accumulation);
+ * their workspace holds fcd_reduce_workspace_bytes() bytes. */
+size_t fcd_reduce_workspace_bytes(void);
+/* out[0] = scale * sum(x) (torch.mean with scale = +-1/n; fcd_solver.py:287,293,318,324) */
+int fcd_sum_scaled(const float* x, float* out, size_t n, float scale, void* workspace,
+                   size_t workspace_bytes, void* stream);
+/* out[0] = mean |a - b| (fcd_solver.py:326,354,359) */
+int fcd_l1_mean(const float* a, const float* b, float* out, size_t n, void* workspace,
+                size_t workspace_bytes, void* stream);
+/* ga (+)= gscale[0]*sign(a-b)/n ; gb likewise with the opposite sign (either may be NULL) */
+int fcd_l1_mean_bwd(const float* a, const float* b, const float* gscale, float* ga, float* gb,
+                    int accumulate, size_t n, void* stream);
+/* F.binary_cross_entropy_with_logits mean (fcd_solver.py:263):
+ * max(x,0) - x*t + log1p(exp(-|x|)) */
+int fcd_bce_logits_mean(const float* logit, const float* target, float* out, size_t n,
+                        void* workspace, size_t workspace_bytes, void* stream);
+int fcd_bce_logits_mean_bwd(const float* logit, const float* target, const float* gscale,
+                            float* glogit, size_t n, void* stream);
+/* x_hat = alpha[n]*a + (1-alpha[n])*b (fcd_solver.py:297) */
+int fcd_lerp_rows(const float* a, const float* b, const float* alpha, float* out, int N,
+                  size_t per_row, void* stream);
+/* WGAN-GP (fcd_solver.py:237-239): norm[n] = sqrt(sum_row g^2); out[0] = mean (norm-1)^2 */
+int fcd_gp_fwd(const float* g, float* norm, float* out, int N, size_t per_row, void* stream);
+/* d out / d g = gscale[0] * 2*(norm-1)/(N*norm) * g */
+int fcd_gp_bwd(const float* g, const float* norm, const float* gscale, float* gg, int N,
+               size_t per_row, void* stream);
+
+/* torch.optim.Adam step (fcd_solver.py:183,186), one flat tensor. */
+int fcd_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1,
+                  float beta2, float eps, int step, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Mask generation (fcd_solver.py:802-807, 762, 771-772).
+ * diff[n][h][w] = mean_c |x_fake - x| / 2 (NCHW inputs);
+ * mask = diff > thr compared in fp32 (uint8 0/1); either output may be NULL.
+ * ------------------------------------------------------------------------- */
+int fcd_diffmap_threshold(const float* x_fake, const float* x, float* diff, uint8_t* mask,
+                          float thr, int N, int C, int H, int W, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FCD_HIP_H */
