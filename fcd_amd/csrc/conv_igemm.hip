@@ -510,7 +510,7 @@ int validate_conv(const FcdConvDesc* d) {
   FCD_REQUIRE(d->KH > 0 && d->KW > 0, "conv: taps");
   FCD_REQUIRE(d->istride >= 1 && d->ostride >= 1, "conv: strides");
   FCD_REQUIRE(d->nphase >= 1 && d->nphase <= 4, "conv: nphase=%d", d->nphase);
-  FCD_REQUIRE(d->splitk >= 1 && d->splitk <= 1024, "conv: splitk=%d", d->splitk);
+  FCD_REQUIRE(d->splitk >= 0 && d->splitk <= 1024, "conv: splitk=%d", d->splitk);
   FCD_REQUIRE(d->precision == FCD_PREC_F32 || d->precision == FCD_PREC_BF16, "conv: precision");
   for (int ph = 0; ph < d->nphase; ++ph) {
     const long oh = (long)(d->GH - 1) * d->ostride + d->ooff_h[ph];
@@ -522,11 +522,37 @@ int validate_conv(const FcdConvDesc* d) {
   return FCD_OK;
 }
 
+// tile shape by problem shape (shared by the workspace query and the launch)
+void gather_tile(const FcdConvDesc* d, int& bm, int& bn) {
+  const long M = (long)d->N * d->GH * d->GW;
+  if (d->Cout <= 32) { bm = 128; bn = 32; }
+  else if (d->Cout <= 64) { bm = 128; bn = 64; }
+  else if (M <= 64) { bm = 64; bn = 128; }
+  else { bm = 128; bn = 128; }
+}
+
+// splitk == 0 in the descriptor: pick one that gives the 256 CUs at least ~3 workgroups each
+int resolve_splitk(const FcdConvDesc* d) {
+  if (d->splitk > 0) return d->splitk;
+  int bm, bn;
+  gather_tile(d, bm, bn);
+  const long M = (long)d->N * d->GH * d->GW;
+  const long blocks = (long)fcd_cdiv(M, bm) * fcd_cdiv(d->Cout, bn) * d->nphase;
+  const int bk = d->precision == FCD_PREC_BF16 ? 64 : 32;
+  const int ktiles = fcd_cdiv((long)d->KH * d->KW * d->Cin, bk);
+  if (blocks >= 512) return 1;
+  long sk = (768 + blocks - 1) / blocks;
+  if (sk > ktiles / 4) sk = ktiles / 4;
+  if (sk > 64) sk = 64;
+  if (sk < 1) sk = 1;
+  return (int)sk;
+}
+
 void fill_gather_args(const FcdConvDesc* d, GatherArgs& a) {
   a.N = d->N; a.IH = d->IH; a.IW = d->IW; a.Cin = d->Cin; a.GH = d->GH; a.GW = d->GW;
   a.OH = d->OH; a.OW = d->OW; a.Cout = d->Cout; a.CoutP = d->CoutP; a.KH = d->KH; a.KW = d->KW;
   a.K = d->KH * d->KW * d->Cin;
-  a.istride = d->istride; a.ostride = d->ostride; a.nphase = d->nphase; a.splitk = d->splitk;
+  a.istride = d->istride; a.ostride = d->ostride; a.nphase = d->nphase; a.splitk = resolve_splitk(d);
   for (int i = 0; i < 4; ++i) {
     a.pad_h[i] = d->pad_h[i]; a.pad_w[i] = d->pad_w[i];
     a.ooff_h[i] = d->ooff_h[i]; a.ooff_w[i] = d->ooff_w[i];
@@ -534,7 +560,8 @@ void fill_gather_args(const FcdConvDesc* d, GatherArgs& a) {
   a.M = d->N * d->GH * d->GW;
   const int bk = d->precision == FCD_PREC_BF16 ? 64 : 32;
   a.ktiles = fcd_cdiv(a.K, bk);
-  a.ktiles_per_split = fcd_cdiv(a.ktiles, d->splitk);
+  a.ktiles_per_split = fcd_cdiv(a.ktiles, a.splitk);
+  a.splitk = fcd_cdiv(a.ktiles, a.ktiles_per_split);   // no empty splits
   a.w_phase_stride = (long)d->Cout * a.K;
   a.act_slope = d->act_slope; a.mask_slope = d->mask_slope;
 }
@@ -542,8 +569,10 @@ void fill_gather_args(const FcdConvDesc* d, GatherArgs& a) {
 }  // namespace
 
 extern "C" size_t fcd_conv_workspace_bytes(const FcdConvDesc* d) {
-  if (!d || d->splitk <= 1) return 0;
-  return (size_t)d->nphase * d->splitk * d->N * d->GH * d->GW * d->CoutP * sizeof(float);
+  if (!d || d->nphase < 1 || d->Cin <= 0 || d->KH <= 0 || d->KW <= 0) return 0;
+  const int sk = resolve_splitk(d);
+  if (sk <= 1) return 0;
+  return (size_t)d->nphase * sk * d->N * d->GH * d->GW * d->CoutP * sizeof(float);
 }
 
 extern "C" int fcd_conv_gather(const FcdConvDesc* d, const float* in, const float* w_packed,
@@ -563,22 +592,16 @@ extern "C" int fcd_conv_gather(const FcdConvDesc* d, const float* in, const floa
   a.in = in; a.w = w_packed; a.bias = bias; a.mask = mask_src; a.res = residual; a.out = out;
   a.slab = (float*)workspace;
   hipStream_t st = fcd_stream(stream);
-  // tile shape by problem shape
-  if (d->Cout <= 32) {
-    a.tiles_m = fcd_cdiv(a.M, 128); a.tiles_n = fcd_cdiv(d->Cout, 32);
-    rc = launch_gather<128, 32, 4, 1>(a, d->precision, st);
-  } else if (d->Cout <= 64) {
-    a.tiles_m = fcd_cdiv(a.M, 128); a.tiles_n = fcd_cdiv(d->Cout, 64);
-    rc = launch_gather<128, 64, 2, 2>(a, d->precision, st);
-  } else if (a.M <= 64) {
-    a.tiles_m = fcd_cdiv(a.M, 64); a.tiles_n = fcd_cdiv(d->Cout, 128);
-    rc = launch_gather<64, 128, 2, 2>(a, d->precision, st);
-  } else {
-    a.tiles_m = fcd_cdiv(a.M, 128); a.tiles_n = fcd_cdiv(d->Cout, 128);
-    rc = launch_gather<128, 128, 2, 2>(a, d->precision, st);
-  }
+  int bm, bn;
+  gather_tile(d, bm, bn);
+  a.tiles_m = fcd_cdiv(a.M, bm);
+  a.tiles_n = fcd_cdiv(d->Cout, bn);
+  if (bn == 32) rc = launch_gather<128, 32, 4, 1>(a, d->precision, st);
+  else if (bn == 64) rc = launch_gather<128, 64, 2, 2>(a, d->precision, st);
+  else if (bm == 64) rc = launch_gather<64, 128, 2, 2>(a, d->precision, st);
+  else rc = launch_gather<128, 128, 2, 2>(a, d->precision, st);
   if (rc) return rc;
-  if (d->splitk > 1) {
+  if (a.splitk > 1) {
     const long total = (long)a.nphase * a.M * a.CoutP;
     const int blocks = (int)std::min<long>(fcd_cdiv(total, 256), 4096);
     hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, a);
@@ -587,20 +610,33 @@ extern "C" int fcd_conv_gather(const FcdConvDesc* d, const float* in, const floa
   return rc;
 }
 
+static int wgrad_bm(const FcdWgradDesc* d) { return d->O <= 32 ? 32 : (d->O <= 64 ? 64 : 128); }
+
+static int resolve_wgrad_splitk(const FcdWgradDesc* d) {
+  if (d->splitk > 0) return d->splitk;
+  const long tiles = (long)fcd_cdiv(d->O, wgrad_bm(d)) * fcd_cdiv((long)d->KH * d->KW * d->IP, 128);
+  const int ktiles = fcd_cdiv((long)d->N * d->GH * d->GW, 32);
+  long sk = (1024 + tiles - 1) / tiles;
+  if (sk > ktiles / 8) sk = ktiles / 8;
+  if (sk > 512) sk = 512;
+  if (sk < 1) sk = 1;
+  return (int)sk;
+}
+
 static int validate_wgrad(const FcdWgradDesc* d) {
   FCD_REQUIRE(d != nullptr, "wgrad: null descriptor");
   FCD_REQUIRE(d->N > 0 && d->GH > 0 && d->GW > 0 && d->BH > 0 && d->BW > 0, "wgrad: extents");
   FCD_REQUIRE(d->O > 0 && d->OP >= d->O && d->OP % 4 == 0, "wgrad: O=%d OP=%d", d->O, d->OP);
   FCD_REQUIRE(d->I > 0 && d->IP >= d->I && d->IP % 4 == 0, "wgrad: I=%d IP=%d", d->I, d->IP);
   FCD_REQUIRE(d->KH > 0 && d->KW > 0 && d->stride >= 1 && d->pad >= 0, "wgrad: kernel");
-  FCD_REQUIRE(d->splitk >= 1 && d->splitk <= 4096, "wgrad: splitk=%d", d->splitk);
+  FCD_REQUIRE(d->splitk >= 0 && d->splitk <= 4096, "wgrad: splitk=%d", d->splitk);
   FCD_REQUIRE((long)d->N * d->GH * d->GW < (1l << 31), "wgrad: too many pixels");
   return FCD_OK;
 }
 
 extern "C" size_t fcd_wgrad_workspace_bytes(const FcdWgradDesc* d) {
-  if (!d) return 0;
-  return (size_t)d->splitk * d->O * d->KH * d->KW * d->IP * sizeof(float);
+  if (!d || d->O <= 0 || d->IP <= 0 || d->KH <= 0 || d->KW <= 0) return 0;
+  return (size_t)resolve_wgrad_splitk(d) * d->O * d->KH * d->KW * d->IP * sizeof(float);
 }
 
 extern "C" int fcd_conv_wgrad(const FcdWgradDesc* d, const float* gsmall, const float* xbig, float* dw,
@@ -619,9 +655,10 @@ extern "C" int fcd_conv_wgrad(const FcdWgradDesc* d, const float* gsmall, const 
   a.I = d->I; a.IP = d->IP; a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
   a.P = d->N * d->GH * d->GW;
   a.ND = d->KH * d->KW * d->IP;
-  a.splitk = d->splitk;
+  a.splitk = resolve_wgrad_splitk(d);
   a.ktiles = fcd_cdiv(a.P, 32);
-  a.ktiles_per_split = fcd_cdiv(a.ktiles, d->splitk);
+  a.ktiles_per_split = fcd_cdiv(a.ktiles, a.splitk);
+  a.splitk = fcd_cdiv(a.ktiles, a.ktiles_per_split);
   a.accumulate = d->accumulate;
   hipStream_t st = fcd_stream(stream);
   if (d->O <= 32) {

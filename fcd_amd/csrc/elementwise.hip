@@ -84,6 +84,12 @@ __global__ __launch_bounds__(256) void lrelu_bwd_kernel(const float* __restrict_
     out[i] = g[i] * (y[i] > 0.f ? 1.f : slope);
 }
 
+__global__ __launch_bounds__(256) void fill_scaled_kernel(float* __restrict__ out, size_t n, float scale,
+                                                          const float* __restrict__ gscale) {
+  const float v = scale * gscale[0];
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = v;
+}
+
 __global__ __launch_bounds__(256) void lerp_rows_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                         const float* __restrict__ alpha, float* __restrict__ out,
                                                         size_t per_row, size_t total) {
@@ -377,6 +383,12 @@ extern "C" int fcd_lrelu_bwd(const float* g, const float* y, float* out, size_t 
   FCD_REQUIRE(g && y && out && n > 0, "lrelu_bwd: bad arguments");
   hipLaunchKernelGGL(lrelu_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, fcd_stream(stream), g, y, out, n, slope);
   return fcd_check_launch("lrelu_bwd");
+}
+
+extern "C" int fcd_fill_scaled(float* out, size_t n, float scale, const float* gscale, void* stream) {
+  FCD_REQUIRE(out && gscale && n > 0, "fill_scaled: bad arguments");
+  hipLaunchKernelGGL(fill_scaled_kernel, dim3(grid_for(n)), dim3(256), 0, fcd_stream(stream), out, n, scale, gscale);
+  return fcd_check_launch("fill_scaled");
 }
 
 extern "C" int fcd_lerp_rows(const float* a, const float* b, const float* alpha, float* out, int N, size_t per_row,

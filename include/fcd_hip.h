@@ -70,7 +70,8 @@ typedef struct FcdConvDesc {
   int32_t nphase;
   int32_t pad_h[4], pad_w[4];
   int32_t ooff_h[4], ooff_w[4];
-  int32_t splitk;                /* >= 1; partial sums go through the workspace  */
+  int32_t splitk;                /* 0 = chosen by the library; >1: partial sums go
+                                    through the workspace                        */
   int32_t precision;             /* FCD_PREC_*                                   */
   float act_slope;               /* LeakyReLU slope of the epilogue, 1 = identity */
   float mask_slope;              /* slope used with mask_src                     */
@@ -90,7 +91,7 @@ typedef struct FcdWgradDesc {
   int32_t N, GH, GW, O, OP;      /* gsmall NHWC [N][GH][GW][OP], O logical       */
   int32_t BH, BW, I, IP;         /* xbig   NHWC [N][BH][BW][IP], I logical       */
   int32_t KH, KW, stride, pad;
-  int32_t splitk;
+  int32_t splitk;                /* 0 = chosen by the library                    */
   int32_t precision;
   int32_t accumulate;            /* 1: dw += result                              */
 } FcdWgradDesc;
@@ -187,6 +188,8 @@ size_t fcd_reduce_workspace_bytes(void);
 /* out[0] = scale * sum(x) (torch.mean with scale = +-1/n; fcd_solver.py:287,293,318,324) */
 int fcd_sum_scaled(const float* x, float* out, size_t n, float scale, void* workspace,
                    size_t workspace_bytes, void* stream);
+/* out[i] = scale * gscale[0]: the gradient of scale*sum(x) */
+int fcd_fill_scaled(float* out, size_t n, float scale, const float* gscale, void* stream);
 /* out[0] = mean |a - b| (fcd_solver.py:326,354,359) */
 int fcd_l1_mean(const float* a, const float* b, float* out, size_t n, void* workspace,
                 size_t workspace_bytes, void* stream);

@@ -162,7 +162,7 @@ def run_config(cfg, store_tensors):
     for k in rlosses:
         worst = max(worst, check(k, olosses[k], rlosses[k], 1e-5))
     for k in rgrads:
-        worst = max(worst, check("dD/" + k, ograds[k], rgrads[k], 1e-3))
+        worst = max(worst, check("dD/" + k, ograds[k], rgrads[k], 2e-2))
     d_loss, d_losses, d_grads = rl, rlosses, rgrads
 
     # ---- G step (fresh modules: same weights, running stats from synth state) ---
@@ -174,7 +174,7 @@ def run_config(cfg, store_tensors):
     for k in rlosses:
         worst = max(worst, check(k, olosses[k], rlosses[k], 1e-5))
     for k in rgrads:
-        worst = max(worst, check("dG/" + k, ograds[k], rgrads[k], 1e-3))
+        worst = max(worst, check("dG/" + k, ograds[k], rgrads[k], 2e-2))
     for k, v in stats_after_g.items():
         worst = max(worst, check("G-step " + k, ns[k], v, 2e-6))
     g_loss, g_losses, g_grads = rl, rlosses, rgrads
@@ -184,6 +184,18 @@ def run_config(cfg, store_tensors):
     b64 = tuple(t.double() for t in batch)
     _, dl64, dg64 = O.d_step(gs64, ds64, b64, alpha.double(), new_stats={})
     _, gl64, gg64 = O.g_step(gs64, ds64, b64, new_stats={})
+    # strongest pin: the reference's own modules in fp64 against the fp64 oracle
+    G, D = ref_modules(gs, ds, cfg)
+    G.double(); D.double()
+    _, _, rdg64 = ref_d_step(G, D, b64, alpha.double())
+    G, D = ref_modules(gs, ds, cfg)
+    G.double(); D.double()
+    _, _, rgg64 = ref_g_step(G, D, b64)
+    pin64 = 0.0
+    for k in rdg64:
+        pin64 = max(pin64, check("fp64 dD/" + k, dg64[k], rdg64[k], 1e-9))
+    for k in rgg64:
+        pin64 = max(pin64, check("fp64 dG/" + k, gg64[k], rgg64[k], 1e-9))
     ref32_vs_64 = {"d": {k: relerr(d_grads[k], dg64[k]) for k in d_grads},
                    "g": {k: relerr(g_grads[k], gg64[k]) for k in g_grads}}
 
@@ -237,6 +249,7 @@ def run_config(cfg, store_tensors):
             "d_grad_norm64": {k: float(v.norm()) for k, v in dg64.items()},
             "g_grad_norm64": {k: float(v.norm()) for k, v in gg64.items()},
             "ref_fp32_vs_fp64_grad_relerr": ref32_vs_64,
+            "oracle_fp64_vs_reference_fp64_worst_relerr": pin64,
             "G_eval_out_norm": float(ref_eval.double().norm()),
             "G_train_out_norm": float(ref_train.double().norm()),
             "diff_sum": float(ref_diff.double().sum()),
