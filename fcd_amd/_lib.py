@@ -1,0 +1,159 @@
+"""ctypes binding of libfcd_hip.so (include/fcd_hip.h).
+
+The product path has no fallback: if the shared library is missing, or a call
+returns a non-zero status, a RuntimeError is raised.  PyTorch is used here only
+for device memory (``tensor.data_ptr()``), the current HIP stream and the
+caching allocator that provides workspaces.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfcd_hip.so")
+
+PREC_F32 = 0
+PREC_BF16 = 1
+
+c_float_p = C.c_void_p  # device pointers travel as opaque addresses
+
+
+class ConvDesc(C.Structure):
+    """Mirror of ``FcdConvDesc``."""
+    _fields_ = [
+        ("N", C.c_int32), ("IH", C.c_int32), ("IW", C.c_int32), ("Cin", C.c_int32),
+        ("GH", C.c_int32), ("GW", C.c_int32),
+        ("OH", C.c_int32), ("OW", C.c_int32), ("Cout", C.c_int32), ("CoutP", C.c_int32),
+        ("KH", C.c_int32), ("KW", C.c_int32),
+        ("istride", C.c_int32), ("ostride", C.c_int32),
+        ("nphase", C.c_int32),
+        ("pad_h", C.c_int32 * 4), ("pad_w", C.c_int32 * 4),
+        ("ooff_h", C.c_int32 * 4), ("ooff_w", C.c_int32 * 4),
+        ("splitk", C.c_int32), ("precision", C.c_int32),
+        ("act_slope", C.c_float), ("mask_slope", C.c_float),
+    ]
+
+
+class WgradDesc(C.Structure):
+    """Mirror of ``FcdWgradDesc``."""
+    _fields_ = [
+        ("N", C.c_int32), ("GH", C.c_int32), ("GW", C.c_int32), ("O", C.c_int32), ("OP", C.c_int32),
+        ("BH", C.c_int32), ("BW", C.c_int32), ("I", C.c_int32), ("IP", C.c_int32),
+        ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
+        ("splitk", C.c_int32), ("precision", C.c_int32), ("accumulate", C.c_int32),
+    ]
+
+
+_P, _I, _F, _Z = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); every symbol declared in include/fcd_hip.h
+PROTOTYPES = {
+    "fcd_last_error": (C.c_char_p, []),
+    "fcd_abi_version": (_I, []),
+    "fcd_init": (_I, [_I]),
+    "fcd_conv_workspace_bytes": (_Z, [C.POINTER(ConvDesc)]),
+    "fcd_conv_gather": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "fcd_wgrad_workspace_bytes": (_Z, [C.POINTER(WgradDesc)]),
+    "fcd_conv_wgrad": (_I, [C.POINTER(WgradDesc), _P, _P, _P, _P, _Z, _P]),
+    "fcd_pack_weight_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "fcd_pack_weight_adj": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "fcd_head_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "fcd_head_dgrad": (_I, [_P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "fcd_head_wgrad": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "fcd_instnorm_workspace_bytes": (_Z, [_I, _I, _I]),
+    "fcd_instnorm_stats": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _P, _Z, _P]),
+    "fcd_instnorm_stats_from_running": (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),
+    "fcd_instnorm_update_running": (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),
+    "fcd_instnorm_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P]),
+    "fcd_instnorm_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P, _Z, _P]),
+    "fcd_g_prologue": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "fcd_g_epilogue_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "fcd_g_epilogue_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "fcd_nchw_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "fcd_nhwc_to_nchw": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "fcd_lrelu_bwd": (_I, [_P, _P, _P, _Z, _F, _P]),
+    "fcd_colsum_workspace_bytes": (_Z, [_Z, _I]),
+    "fcd_colsum": (_I, [_P, _P, _I, _Z, _I, _P, _Z, _P]),
+    "fcd_reduce_workspace_bytes": (_Z, []),
+    "fcd_sum_scaled": (_I, [_P, _P, _Z, _F, _P, _Z, _P]),
+    "fcd_fill_scaled": (_I, [_P, _Z, _F, _P, _P]),
+    "fcd_l1_mean": (_I, [_P, _P, _P, _Z, _P, _Z, _P]),
+    "fcd_l1_mean_bwd": (_I, [_P, _P, _P, _P, _P, _I, _Z, _P]),
+    "fcd_bce_logits_mean": (_I, [_P, _P, _P, _Z, _P, _Z, _P]),
+    "fcd_bce_logits_mean_bwd": (_I, [_P, _P, _P, _P, _Z, _P]),
+    "fcd_lerp_rows": (_I, [_P, _P, _P, _P, _I, _Z, _P]),
+    "fcd_gp_fwd": (_I, [_P, _P, _P, _I, _Z, _P]),
+    "fcd_gp_bwd": (_I, [_P, _P, _P, _P, _I, _Z, _P]),
+    "fcd_adam_step": (_I, [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _I, _P]),
+    "fcd_diffmap_threshold": (_I, [_P, _P, _P, _P, _F, _I, _I, _I, _I, _P]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load the HIP library once; raise loudly when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"fcd_amd: {LIB_PATH} is missing. Build it with `make` (hipcc --offload-arch=gfx950); "
+            "there is no CPU or stock-PyTorch fallback for the FCD hot path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)   # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.fcd_abi_version() != 1:
+        raise RuntimeError("fcd_amd: libfcd_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().fcd_last_error().decode(errors="replace")
+        raise RuntimeError(f"libfcd_hip {what} failed (status {rc}): {msg}")
+
+
+def ptr(t: Optional[torch.Tensor]):
+    """Device address of a contiguous fp32 tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class _Workspace:
+    """One growing byte buffer per device; all calls are stream-ordered, so it is reused."""
+
+    def __init__(self):
+        self.buf = {}
+
+    def get(self, nbytes: int, device) -> torch.Tensor:
+        key = torch.device(device).index
+        b = self.buf.get(key)
+        if b is None or b.numel() < nbytes:
+            b = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+            self.buf[key] = b
+        return b
+
+
+workspace = _Workspace()
+
+
+def require_gpu_tensor(t: torch.Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(f"fcd_amd: {name} must live on the GPU (got {t.device}); the HIP path has no CPU fallback")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"fcd_amd: {name} must be float32 (got {t.dtype})")
+    if not t.is_contiguous():
+        raise RuntimeError(f"fcd_amd: {name} must be contiguous")

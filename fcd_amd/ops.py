@@ -1,0 +1,399 @@
+"""Thin Python wrappers over the C ABI: allocate outputs, pass raw pointers.
+
+Every function here launches HIP kernels from libfcd_hip.so on the current
+stream.  Tensors are fp32; "nhwc" tensors are [N, H, W, CP] with CP a multiple
+of 4 (pad channels are zero).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+from ._lib import ConvDesc, WgradDesc, check, ptr, stream
+
+LRELU_SLOPE = 0.01
+IN_EPS = 1e-5
+IN_MOMENTUM = 0.1
+
+
+def pad4(c: int) -> int:
+    return (c + 3) // 4 * 4
+
+
+def _ws(nbytes: int, device):
+    if nbytes <= 0:
+        return None, 0
+    b = L.workspace.get(nbytes, device)
+    return b.data_ptr(), b.numel()
+
+
+# --------------------------------------------------------------------------- #
+# convolution geometry (host logic; unit-tested on CPU)
+# --------------------------------------------------------------------------- #
+@dataclass(frozen=True)
+class ConvGeom:
+    """The equivalent convolution W[O][I][k][k], stride s, padding p.
+
+    nn.Conv2d(I, O, k, s, p) uses it directly; nn.ConvTranspose2d(O, I, k, s, p)
+    (weight [O][I][k][k] in torch's [C_in, C_out, kh, kw] order) is its adjoint.
+    """
+    O: int
+    I: int
+    k: int
+    s: int
+    p: int
+
+    @property
+    def OP(self) -> int:
+        return pad4(self.O)
+
+    @property
+    def IP(self) -> int:
+        return pad4(self.I)
+
+    def small_hw(self, bh: int, bw: int):
+        """Spatial size on the conv-output ("small") side for a big-side size."""
+        return (bh + 2 * self.p - self.k) // self.s + 1, (bw + 2 * self.p - self.k) // self.s + 1
+
+    def big_hw(self, sh: int, sw: int):
+        """Spatial size on the conv-input ("big") side: ConvTranspose2d output size."""
+        return (sh - 1) * self.s - 2 * self.p + self.k, (sw - 1) * self.s - 2 * self.p + self.k
+
+    def fwd_desc(self, n: int, bh: int, bw: int, precision: int = L.PREC_F32, act_slope: float = 1.0,
+                 mask_slope: float = 1.0) -> ConvDesc:
+        """big [n,bh,bw,IP] -> small [n,sh,sw,OP]: the conv itself."""
+        sh, sw = self.small_hw(bh, bw)
+        d = ConvDesc()
+        d.N, d.IH, d.IW, d.Cin = n, bh, bw, self.IP
+        d.GH, d.GW, d.OH, d.OW = sh, sw, sh, sw
+        d.Cout, d.CoutP = self.O, self.OP
+        d.KH = d.KW = self.k
+        d.istride, d.ostride, d.nphase = self.s, 1, 1
+        d.pad_h[0] = d.pad_w[0] = self.p
+        d.splitk, d.precision = 0, precision
+        d.act_slope, d.mask_slope = act_slope, mask_slope
+        return d
+
+    def adj_desc(self, n: int, sh: int, sw: int, precision: int = L.PREC_F32, act_slope: float = 1.0,
+                 mask_slope: float = 1.0) -> ConvDesc:
+        """small [n,sh,sw,OP] -> big [n,bh,bw,IP]: the adjoint (data gradient / transposed conv)."""
+        bh, bw = self.big_hw(sh, sw)
+        d = ConvDesc()
+        d.N, d.IH, d.IW, d.Cin = n, sh, sw, self.OP
+        d.OH, d.OW, d.Cout, d.CoutP = bh, bw, self.I, self.IP
+        d.istride = 1
+        if self.s == 1:
+            d.GH, d.GW = bh, bw
+            d.KH = d.KW = self.k
+            d.ostride, d.nphase = 1, 1
+            d.pad_h[0] = d.pad_w[0] = self.k - 1 - self.p
+        elif self.s == 2 and self.k == 4 and self.p == 1:
+            d.GH, d.GW = sh, sw
+            d.KH = d.KW = 2
+            d.ostride, d.nphase = 2, 4
+            for ph in range(4):
+                py, px = ph >> 1, ph & 1
+                d.pad_h[ph], d.pad_w[ph] = 1 - py, 1 - px
+                d.ooff_h[ph], d.ooff_w[ph] = py, px
+        else:
+            raise NotImplementedError(f"adjoint of conv k={self.k} s={self.s} p={self.p}")
+        d.splitk, d.precision = 0, precision
+        d.act_slope, d.mask_slope = act_slope, mask_slope
+        return d
+
+    def wgrad_desc(self, n: int, bh: int, bw: int, precision: int = L.PREC_F32, accumulate: bool = False) -> WgradDesc:
+        sh, sw = self.small_hw(bh, bw)
+        d = WgradDesc()
+        d.N, d.GH, d.GW, d.O, d.OP = n, sh, sw, self.O, self.OP
+        d.BH, d.BW, d.I, d.IP = bh, bw, self.I, self.IP
+        d.KH = d.KW = self.k
+        d.stride, d.pad = self.s, self.p
+        d.splitk, d.precision, d.accumulate = 0, precision, int(accumulate)
+        return d
+
+    def adj_phases(self) -> int:
+        return 1 if self.s == 1 else 4
+
+    def adj_taps(self) -> int:
+        return self.k if self.s == 1 else 2
+
+
+def conv_gather(d: ConvDesc, x: torch.Tensor, w_packed: torch.Tensor, bias=None, mask=None, residual=None,
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    lib = L.load()
+    exp_in = (d.N, d.IH, d.IW, d.Cin)
+    if tuple(x.shape) != exp_in:
+        raise RuntimeError(f"conv_gather: input {tuple(x.shape)} != descriptor {exp_in}")
+    K = d.KH * d.KW * d.Cin
+    if w_packed.numel() != d.nphase * d.Cout * K:
+        raise RuntimeError(f"conv_gather: packed weight has {w_packed.numel()} elements, expected {d.nphase * d.Cout * K}")
+    oshape = (d.N, d.OH, d.OW, d.CoutP)
+    if out is None:
+        out = torch.empty(oshape, dtype=torch.float32, device=x.device)
+    elif tuple(out.shape) != oshape:
+        raise RuntimeError(f"conv_gather: out {tuple(out.shape)} != {oshape}")
+    for t, nm in ((mask, "mask"), (residual, "residual")):
+        if t is not None and tuple(t.shape) != oshape:
+            raise RuntimeError(f"conv_gather: {nm} {tuple(t.shape)} != {oshape}")
+    if bias is not None and bias.numel() != d.Cout:
+        raise RuntimeError("conv_gather: bias size")
+    L.require_gpu_tensor(x, "x")
+    L.require_gpu_tensor(w_packed, "w_packed")
+    wp, wn = _ws(lib.fcd_conv_workspace_bytes(C.byref(d)), x.device)
+    check(lib.fcd_conv_gather(C.byref(d), ptr(x), ptr(w_packed), ptr(bias), ptr(mask), ptr(residual), ptr(out),
+                              wp, wn, stream()), "conv_gather")
+    return out
+
+
+def conv_wgrad(d: WgradDesc, gsmall: torch.Tensor, xbig: torch.Tensor, dw: Optional[torch.Tensor] = None) -> torch.Tensor:
+    lib = L.load()
+    if tuple(gsmall.shape) != (d.N, d.GH, d.GW, d.OP):
+        raise RuntimeError(f"conv_wgrad: gsmall {tuple(gsmall.shape)} != {(d.N, d.GH, d.GW, d.OP)}")
+    if tuple(xbig.shape) != (d.N, d.BH, d.BW, d.IP):
+        raise RuntimeError(f"conv_wgrad: xbig {tuple(xbig.shape)} != {(d.N, d.BH, d.BW, d.IP)}")
+    if dw is None:
+        if d.accumulate:
+            raise RuntimeError("conv_wgrad: accumulate needs dw")
+        dw = torch.empty((d.O, d.I, d.KH, d.KW), dtype=torch.float32, device=xbig.device)
+    elif dw.numel() != d.O * d.I * d.KH * d.KW:
+        raise RuntimeError("conv_wgrad: dw size")
+    L.require_gpu_tensor(gsmall, "gsmall")
+    L.require_gpu_tensor(xbig, "xbig")
+    L.require_gpu_tensor(dw, "dw")
+    wp, wn = _ws(lib.fcd_wgrad_workspace_bytes(C.byref(d)), xbig.device)
+    check(lib.fcd_conv_wgrad(C.byref(d), ptr(gsmall), ptr(xbig), ptr(dw), wp, wn, stream()), "conv_wgrad")
+    return dw
+
+
+def pack_weight_fwd(w: torch.Tensor, g: ConvGeom) -> torch.Tensor:
+    L.require_gpu_tensor(w, "weight")
+    out = torch.empty((g.O, g.k, g.k, g.IP), dtype=torch.float32, device=w.device)
+    check(L.load().fcd_pack_weight_fwd(ptr(w), ptr(out), g.O, g.I, g.IP, g.k, g.k, stream()), "pack_weight_fwd")
+    return out
+
+
+def pack_weight_adj(w: torch.Tensor, g: ConvGeom) -> torch.Tensor:
+    L.require_gpu_tensor(w, "weight")
+    t = g.adj_taps()
+    out = torch.empty((g.adj_phases(), g.I, t, t, g.OP), dtype=torch.float32, device=w.device)
+    check(L.load().fcd_pack_weight_adj(ptr(w), ptr(out), g.O, g.OP, g.I, g.k, g.k, g.s, stream()), "pack_weight_adj")
+    return out
+
+
+# --------------------------------------------------------------------------- #
+# Discriminator heads
+# --------------------------------------------------------------------------- #
+def head_fwd(x: torch.Tensor, w_packed: torch.Tensor, O: int, k: int, pad: int) -> torch.Tensor:
+    n, ih, iw, ip = x.shape
+    oh, ow = ih + 2 * pad - k + 1, iw + 2 * pad - k + 1
+    out = torch.empty((n, O, oh, ow), dtype=torch.float32, device=x.device)
+    check(L.load().fcd_head_fwd(ptr(x), ptr(w_packed), ptr(out), n, ih, iw, ip, O, k, k, pad, stream()), "head_fwd")
+    return out
+
+
+def head_dgrad(gout: torch.Tensor, w_packed: torch.Tensor, din: torch.Tensor, mask, mask_slope: float,
+               accumulate: bool, k: int, pad: int) -> torch.Tensor:
+    n, ih, iw, ip = din.shape
+    O = gout.shape[1]
+    check(L.load().fcd_head_dgrad(ptr(gout), ptr(w_packed), ptr(din), ptr(mask), mask_slope, int(accumulate), n, ih, iw,
+                                  ip, O, k, k, pad, stream()), "head_dgrad")
+    return din
+
+
+def head_wgrad(gout: torch.Tensor, x: torch.Tensor, I: int, k: int, pad: int, dw: Optional[torch.Tensor] = None,
+               accumulate: bool = False) -> torch.Tensor:
+    n, ih, iw, ip = x.shape
+    O = gout.shape[1]
+    if dw is None:
+        dw = torch.empty((O, I, k, k), dtype=torch.float32, device=x.device)
+    check(L.load().fcd_head_wgrad(ptr(gout), ptr(x), ptr(dw), int(accumulate), n, ih, iw, I, ip, O, k, k, pad, stream()),
+          "head_wgrad")
+    return dw
+
+
+# --------------------------------------------------------------------------- #
+# instance norm
+# --------------------------------------------------------------------------- #
+def instnorm_stats(z: torch.Tensor, want_var: bool = False):
+    n, h, w, c = z.shape
+    lib = L.load()
+    mean = torch.empty((n, c), dtype=torch.float32, device=z.device)
+    rstd = torch.empty_like(mean)
+    varu = torch.empty_like(mean) if want_var else None
+    wp, wn = _ws(lib.fcd_instnorm_workspace_bytes(n, h * w, c), z.device)
+    check(lib.fcd_instnorm_stats(ptr(z), ptr(mean), ptr(rstd), ptr(varu), n, h * w, c, IN_EPS, wp, wn, stream()),
+          "instnorm_stats")
+    return mean, rstd, varu
+
+
+def instnorm_stats_from_running(rm: torch.Tensor, rv: torch.Tensor, n: int):
+    c = rm.numel()
+    mean = torch.empty((n, c), dtype=torch.float32, device=rm.device)
+    rstd = torch.empty_like(mean)
+    check(L.load().fcd_instnorm_stats_from_running(ptr(rm), ptr(rv), ptr(mean), ptr(rstd), n, c, IN_EPS, stream()),
+          "stats_from_running")
+    return mean, rstd
+
+
+def instnorm_update_running(rm, rv, mean, varu):
+    n, c = mean.shape
+    check(L.load().fcd_instnorm_update_running(ptr(rm), ptr(rv), ptr(mean), ptr(varu), n, c, IN_MOMENTUM, stream()),
+          "update_running")
+
+
+def instnorm_apply(z, mean, rstd, gamma, beta, act_slope: float, residual=None, out=None):
+    n, h, w, c = z.shape
+    if out is None:
+        out = torch.empty_like(z)
+    check(L.load().fcd_instnorm_apply(ptr(z), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(residual), ptr(out), n,
+                                      h * w, c, act_slope, stream()), "instnorm_apply")
+    return out
+
+
+def instnorm_bwd(gy, y, z, mean, rstd, gamma, act_slope: float, use_running: bool, want_affine: bool = True):
+    n, h, w, c = z.shape
+    lib = L.load()
+    dz = torch.empty_like(z)
+    dgamma = torch.empty_like(gamma) if want_affine else None
+    dbeta = torch.empty_like(gamma) if want_affine else None
+    wp, wn = _ws(lib.fcd_instnorm_workspace_bytes(n, h * w, c), z.device)
+    check(lib.fcd_instnorm_bwd(ptr(gy), ptr(y), ptr(z), ptr(mean), ptr(rstd), ptr(gamma), ptr(dz), ptr(dgamma),
+                               ptr(dbeta), 0, n, h * w, c, act_slope, int(use_running), wp, wn, stream()), "instnorm_bwd")
+    return dz, dgamma, dbeta
+
+
+# --------------------------------------------------------------------------- #
+# layout / Generator prologue + epilogue
+# --------------------------------------------------------------------------- #
+def g_prologue(x: torch.Tensor, c: torch.Tensor, cp: int) -> torch.Tensor:
+    n, ch, h, w = x.shape
+    out = torch.empty((n, h, w, cp), dtype=torch.float32, device=x.device)
+    check(L.load().fcd_g_prologue(ptr(x), ptr(c), ptr(out), n, ch, c.shape[1], cp, h, w, stream()), "g_prologue")
+    return out
+
+
+def nchw_to_nhwc(x: torch.Tensor, cp: int) -> torch.Tensor:
+    n, ch, h, w = x.shape
+    out = torch.empty((n, h, w, cp), dtype=torch.float32, device=x.device)
+    check(L.load().fcd_nchw_to_nhwc(ptr(x), ptr(out), n, ch, cp, h, w, stream()), "nchw_to_nhwc")
+    return out
+
+
+def nhwc_to_nchw(x: torch.Tensor, c: int, out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+    n, h, w, cp = x.shape
+    if out is None:
+        out = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
+    check(L.load().fcd_nhwc_to_nchw(ptr(x), ptr(out), int(accumulate), n, c, cp, h, w, stream()), "nhwc_to_nchw")
+    return out
+
+
+def g_epilogue_fwd(delta: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    n, ch, h, w = x.shape
+    out = torch.empty_like(x)
+    check(L.load().fcd_g_epilogue_fwd(ptr(delta), ptr(x), ptr(out), n, ch, delta.shape[3], h, w, stream()), "g_epilogue_fwd")
+    return out
+
+
+def g_epilogue_bwd(gout, x, x_fake, cp: int, gx: Optional[torch.Tensor]):
+    n, ch, h, w = x.shape
+    gdelta = torch.empty((n, h, w, cp), dtype=torch.float32, device=x.device)
+    check(L.load().fcd_g_epilogue_bwd(ptr(gout), ptr(x), ptr(x_fake), ptr(gdelta), ptr(gx), 0, n, ch, cp, h, w, stream()),
+          "g_epilogue_bwd")
+    return gdelta
+
+
+# --------------------------------------------------------------------------- #
+# elementwise / reductions
+# --------------------------------------------------------------------------- #
+def colsum(x2d_rows: int, x: torch.Tensor, c: int, out: Optional[torch.Tensor] = None, accumulate: bool = False):
+    lib = L.load()
+    if out is None:
+        out = torch.empty((c,), dtype=torch.float32, device=x.device)
+    wp, wn = _ws(lib.fcd_colsum_workspace_bytes(x2d_rows, c), x.device)
+    check(lib.fcd_colsum(ptr(x), ptr(out), int(accumulate), x2d_rows, c, wp, wn, stream()), "colsum")
+    return out
+
+
+def _red_ws(device):
+    return _ws(L.load().fcd_reduce_workspace_bytes(), device)
+
+
+def sum_scaled(x: torch.Tensor, scale: float) -> torch.Tensor:
+    out = torch.empty((), dtype=torch.float32, device=x.device)
+    wp, wn = _red_ws(x.device)
+    check(L.load().fcd_sum_scaled(ptr(x), ptr(out), x.numel(), scale, wp, wn, stream()), "sum_scaled")
+    return out
+
+
+def fill_scaled(shape, scale: float, gscale: torch.Tensor) -> torch.Tensor:
+    out = torch.empty(shape, dtype=torch.float32, device=gscale.device)
+    check(L.load().fcd_fill_scaled(ptr(out), out.numel(), scale, ptr(gscale), stream()), "fill_scaled")
+    return out
+
+
+def l1_mean(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    out = torch.empty((), dtype=torch.float32, device=a.device)
+    wp, wn = _red_ws(a.device)
+    check(L.load().fcd_l1_mean(ptr(a), ptr(b), ptr(out), a.numel(), wp, wn, stream()), "l1_mean")
+    return out
+
+
+def l1_mean_bwd(a, b, gscale, want_a: bool, want_b: bool):
+    ga = torch.empty_like(a) if want_a else None
+    gb = torch.empty_like(b) if want_b else None
+    check(L.load().fcd_l1_mean_bwd(ptr(a), ptr(b), ptr(gscale), ptr(ga), ptr(gb), 0, a.numel(), stream()), "l1_mean_bwd")
+    return ga, gb
+
+
+def bce_logits_mean(logit, target) -> torch.Tensor:
+    out = torch.empty((), dtype=torch.float32, device=logit.device)
+    wp, wn = _red_ws(logit.device)
+    check(L.load().fcd_bce_logits_mean(ptr(logit), ptr(target), ptr(out), logit.numel(), wp, wn, stream()), "bce_logits_mean")
+    return out
+
+
+def bce_logits_mean_bwd(logit, target, gscale):
+    g = torch.empty_like(logit)
+    check(L.load().fcd_bce_logits_mean_bwd(ptr(logit), ptr(target), ptr(gscale), ptr(g), logit.numel(), stream()),
+          "bce_logits_mean_bwd")
+    return g
+
+
+def lerp_rows(a, b, alpha):
+    out = torch.empty_like(a)
+    n = a.shape[0]
+    check(L.load().fcd_lerp_rows(ptr(a), ptr(b), ptr(alpha), ptr(out), n, a.numel() // n, stream()), "lerp_rows")
+    return out
+
+
+def gp_fwd(g: torch.Tensor):
+    n = g.shape[0]
+    norm = torch.empty((n,), dtype=torch.float32, device=g.device)
+    out = torch.empty((), dtype=torch.float32, device=g.device)
+    check(L.load().fcd_gp_fwd(ptr(g), ptr(norm), ptr(out), n, g.numel() // n, stream()), "gp_fwd")
+    return out, norm
+
+
+def gp_bwd(g, norm, gscale):
+    gg = torch.empty_like(g)
+    n = g.shape[0]
+    check(L.load().fcd_gp_bwd(ptr(g), ptr(norm), ptr(gscale), ptr(gg), n, g.numel() // n, stream()), "gp_bwd")
+    return gg
+
+
+def adam_step(p, g, m, v, lr: float, beta1: float, beta2: float, eps: float, step: int) -> None:
+    check(L.load().fcd_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, step, stream()),
+          "adam_step")
+
+
+def diffmap_threshold(x_fake, x, thr: Optional[float], want_diff: bool = True):
+    n, c, h, w = x.shape
+    diff = torch.empty((n, h, w), dtype=torch.float32, device=x.device) if want_diff else None
+    mask = torch.empty((n, h, w), dtype=torch.uint8, device=x.device) if thr is not None else None
+    check(L.load().fcd_diffmap_threshold(ptr(x_fake), ptr(x), ptr(diff), ptr(mask), 0.0 if thr is None else float(thr),
+                                         n, c, h, w, stream()), "diffmap_threshold")
+    return diff, mask
