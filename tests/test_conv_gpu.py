@@ -1,0 +1,109 @@
+"""HIP implicit-GEMM convolutions (through the C ABI) against torch's CPU convolutions.
+
+fp32 MFMA path: rel-err <= 1e-5 per tensor (the bar of the full step is 1e-4);
+bf16 MFMA path: rel-err <= 1e-2 (BASELINE.json north_star tolerances).
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import relerr
+
+pytestmark = pytest.mark.gpu
+
+TOL = {0: 1e-5, 1: 1e-2}
+
+# (O, I, k, s, p, N, H, W)
+GEOMS = [
+    (64, 11, 7, 1, 3, 2, 20, 24),      # G first conv (Cin 11 -> 12 physical)
+    (128, 64, 4, 2, 1, 2, 16, 16),     # down-sampling
+    (256, 256, 3, 1, 1, 3, 8, 8),      # residual block conv
+    (10, 64, 7, 1, 3, 2, 12, 12),      # G last conv (Cout 10)
+    (96, 40, 3, 1, 1, 1, 9, 7),        # ragged sizes
+    (512, 256, 4, 2, 1, 4, 4, 4),      # D deep layer: tiny M, split-K
+    (16, 8, 4, 2, 1, 2, 32, 32),       # tiny channels
+]
+
+
+def to_nhwc(t, cp):
+    n, c, h, w = t.shape
+    out = torch.zeros(n, h, w, cp)
+    out[..., :c] = t.permute(0, 2, 3, 1)
+    return out.contiguous()
+
+
+def from_nhwc(t, c):
+    return t[..., :c].permute(0, 3, 1, 2).contiguous()
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("geom", GEOMS)
+def test_conv_forward(dev, geom, prec):
+    from fcd_amd import ops
+    O, I, k, s, p, N, H, W = geom
+    g = ops.ConvGeom(O, I, k, s, p)
+    torch.manual_seed(1)
+    x = torch.randn(N, I, H, W)
+    w = torch.randn(O, I, k, k) / (I * k * k) ** 0.5
+    b = torch.randn(O)
+    ref = F.leaky_relu(F.conv2d(x, w, b, s, p), 0.01)
+    xd = to_nhwc(x, g.IP).to(dev)
+    wf = ops.pack_weight_fwd(w.to(dev), g)
+    d = g.fwd_desc(N, H, W, precision=prec, act_slope=0.01)
+    out = ops.conv_gather(d, xd, wf, bias=b.to(dev))
+    torch.cuda.synchronize()
+    assert relerr(from_nhwc(out.cpu(), O), ref) <= TOL[prec]
+    assert float(out[..., O:].abs().sum()) == 0.0   # pad channels stay zero
+    # explicit split-K gives the same answer
+    d2 = g.fwd_desc(N, H, W, precision=prec, act_slope=0.01)
+    d2.splitk = 3
+    out2 = ops.conv_gather(d2, xd, wf, bias=b.to(dev))
+    assert relerr(from_nhwc(out2.cpu(), O), ref) <= TOL[prec]
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("geom", GEOMS)
+def test_conv_adjoint(dev, geom, prec):
+    """Data gradient of the conv == ConvTranspose2d forward with the same weight."""
+    from fcd_amd import ops
+    O, I, k, s, p, N, H, W = geom
+    g = ops.ConvGeom(O, I, k, s, p)
+    sh, sw = g.small_hw(H, W)
+    bh, bw = g.big_hw(sh, sw)
+    torch.manual_seed(2)
+    gy = torch.randn(N, O, sh, sw)
+    w = torch.randn(O, I, k, k) / (O * k * k) ** 0.5
+    ref = F.conv_transpose2d(gy, w, None, s, p)
+    assert ref.shape[2:] == (bh, bw)
+    mask = torch.randn(N, I, bh, bw)
+    res = torch.randn(N, I, bh, bw)
+    ref2 = ref * torch.where(mask > 0, 1.0, 0.01) + res
+    wa = ops.pack_weight_adj(w.to(dev), g)
+    d = g.adj_desc(N, sh, sw, precision=prec, mask_slope=0.01)
+    out = ops.conv_gather(d, to_nhwc(gy, g.OP).to(dev), wa)
+    assert relerr(from_nhwc(out.cpu(), I), ref) <= TOL[prec]
+    out2 = ops.conv_gather(d, to_nhwc(gy, g.OP).to(dev), wa, mask=to_nhwc(mask, g.IP).to(dev),
+                           residual=to_nhwc(res, g.IP).to(dev))
+    assert relerr(from_nhwc(out2.cpu(), I), ref2) <= TOL[prec]
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("geom", GEOMS)
+def test_conv_wgrad(dev, geom, prec):
+    from fcd_amd import ops
+    O, I, k, s, p, N, H, W = geom
+    g = ops.ConvGeom(O, I, k, s, p)
+    sh, sw = g.small_hw(H, W)
+    torch.manual_seed(3)
+    x = torch.randn(N, I, H, W)
+    gy = torch.randn(N, O, sh, sw)
+    w = torch.zeros(O, I, k, k, requires_grad=True)
+    (F.conv2d(x, w, None, s, p) * gy).sum().backward()
+    ref = w.grad
+    d = g.wgrad_desc(N, H, W, precision=prec)
+    dw = ops.conv_wgrad(d, to_nhwc(gy, g.OP).to(dev), to_nhwc(x, g.IP).to(dev))
+    assert relerr(dw.cpu(), ref) <= TOL[prec]
+    d.accumulate = 1
+    d.splitk = 2
+    dw2 = ops.conv_wgrad(d, to_nhwc(gy, g.OP).to(dev), to_nhwc(x, g.IP).to(dev), dw.clone())
+    assert relerr(dw2.cpu(), 2 * ref) <= TOL[prec]
