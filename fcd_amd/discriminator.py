@@ -1,0 +1,229 @@
+"""PatchGAN Discriminator of the Fixed-Point GAN on the HIP kernels.
+
+Drop-in for the reference ``Discriminator`` (``models/fixed_point_gan.py:100-144``):
+same constructor and ``forward(x) -> (out_src, out_cls, [feat])``, same state_dict
+keys (``features.{i}.0.{weight,bias}``, ``main.{j}.0.{weight,bias}``,
+``conv1.weight``, ``conv2.weight``).
+
+Autograd structure: forward is one node; its backward is itself a differentiable
+node (``_DBackwardFn``), because the WGAN-GP term (``fcd_solver.py:227-239``)
+differentiates the input gradient again.  D has no norm layers and LeakyReLU has
+zero second derivative, so the backward-of-backward consists of forward
+convolutions of the incoming "grad of grad" and weight-gradient GEMMs against the
+saved masked output gradients -- all explicit HIP launches, no autograd tracing
+of elementary ops.
+"""
+from __future__ import annotations
+
+import contextlib
+import threading
+from typing import List, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import ops
+from .generator import ConvParams, _act_slope
+from .ops import ConvGeom
+
+_state = threading.local()
+
+
+@contextlib.contextmanager
+def input_grad_only():
+    """Inside this context D's backward skips parameter gradients (the GP's
+    ``autograd.grad(y, x, create_graph=True)`` only asks for d y / d x)."""
+    prev = getattr(_state, "input_only", False)
+    _state.input_only = True
+    try:
+        yield
+    finally:
+        _state.input_only = prev
+
+
+class _ConvAct(nn.Sequential):
+    """``Sequential(Conv2d, act)``: index 0 holds the parameters (key ``*.0.weight``)."""
+
+    def __init__(self, cin, cout):
+        super().__init__(ConvParams((cout, cin, 4, 4), cin * 16, bias=True), nn.Identity())
+
+
+class Discriminator(nn.Module):
+    """Discriminator network with PatchGAN (HIP).  Reference: ``fixed_point_gan.py:100-144``."""
+
+    def __init__(self, image_size=128, conv_dim=64, c_dim=5, repeat_num=6, num_channels=3, activation="lrelu",
+                 n_feature_layers=4, interm_non_act=False, use_attention=False):
+        super().__init__()
+        if interm_non_act or use_attention:
+            # off by default (fcd_main.py:144,147); outside the hot path
+            raise NotImplementedError("interm_non_act / use_attention have no HIP path")
+        self.slope = _act_slope(activation)
+        if self.slope <= 0.0:
+            raise NotImplementedError("D needs an activation with positive slope (masks come from the output sign)")
+        self.image_size, self.c_dim, self.num_channels = image_size, c_dim, num_channels
+        self.precision = L.PREC_F32
+        layers = []
+        geoms = []
+        cin, cout = num_channels, conv_dim
+        for _ in range(repeat_num):
+            layers.append(_ConvAct(cin, cout))
+            geoms.append(ConvGeom(cout, cin, 4, 2, 1))
+            cin, cout = cout, cout * 2
+        ks = int(image_size / np.power(2, repeat_num))
+        self.features = nn.ModuleList(layers[:n_feature_layers])
+        rest = layers[n_feature_layers:]
+        self.main = nn.Sequential(*rest) if len(rest) > 0 else nn.Identity()
+        self.conv1 = ConvParams((1, cin, 3, 3), cin * 9)
+        self.conv2 = ConvParams((c_dim, cin, ks, ks), cin * ks * ks)
+        self._convs = [m[0] for m in layers]
+        self._geoms = geoms
+        self._n_feat = min(n_feature_layers, len(layers))
+        self._g1 = ConvGeom(1, cin, 3, 1, 1)
+        self._g2 = ConvGeom(c_dim, cin, ks, 1, 0)
+
+    def _flat_params(self):
+        out = []
+        for cv in self._convs:
+            out += [cv.weight, cv.bias]
+        return out + [self.conv1.weight, self.conv2.weight]
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("fcd_amd.Discriminator runs on the MI355X HIP path only")
+        x = x.contiguous().float()
+        out_src, out_cls, feat = _DiscriminatorFn.apply(self, x, *self._flat_params())
+        return out_src, out_cls.view(out_cls.size(0), out_cls.size(1)), [feat]
+
+
+class _DiscriminatorFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mod: Discriminator, x, *params):
+        L.require_gpu_tensor(x, "x")
+        n, ch, h, w = x.shape
+        if ch != mod.num_channels:
+            raise RuntimeError(f"Discriminator: expected {mod.num_channels} bands")
+        prec = mod.precision
+        acts = [ops.nchw_to_nhwc(x, mod._geoms[0].IP)]
+        for li, (cv, g) in enumerate(zip(mod._convs, mod._geoms)):
+            a = acts[-1]
+            d = g.fwd_desc(n, a.shape[1], a.shape[2], precision=prec, act_slope=mod.slope)
+            acts.append(ops.conv_gather(d, a, cv.packed("fwd", g), bias=params[2 * li + 1]))
+        top = acts[-1]
+        if top.shape[1] < mod._g2.k or top.shape[2] < mod._g2.k:
+            raise RuntimeError("Discriminator: input smaller than image_size")
+        out_src = ops.head_fwd(top, mod.conv1.packed("fwd", mod._g1), 1, 3, 1)
+        out_cls = ops.head_fwd(top, mod.conv2.packed("fwd", mod._g2), mod.c_dim, mod._g2.k, 0)
+        feat = ops.nhwc_to_nchw(acts[mod._n_feat], mod._geoms[mod._n_feat - 1].O)
+        ctx.mod, ctx.acts, ctx.prec = mod, acts, prec
+        ctx.set_materialize_grads(False)
+        ctx.x_shape = x.shape
+        return out_src, out_cls, feat
+
+    @staticmethod
+    def backward(ctx, g_src, g_cls, g_feat):
+        mod = ctx.mod
+        needs = ctx.needs_input_grad
+        want_params = any(needs[2:]) and not getattr(_state, "input_only", False)
+        outs = _DBackwardFn.apply(mod, ctx.acts, ctx.prec, needs[1], want_params, g_src, g_cls, g_feat,
+                                  *mod._flat_params())
+        gx = outs[0]
+        gparams = outs[1:]
+        res = [None, gx if needs[1] else None]
+        for i, gp in enumerate(gparams):
+            res.append(gp if (want_params and needs[2 + i]) else None)
+        return tuple(res)
+
+
+class _DBackwardFn(torch.autograd.Function):
+    """(g_src, g_cls, g_feat, W...) -> (d x, d W...): D's first-order backward as a node."""
+
+    @staticmethod
+    def forward(ctx, mod: Discriminator, acts, prec, want_x, want_params, g_src, g_cls, g_feat, *params):
+        n = acts[0].shape[0]
+        slope = mod.slope
+        top = acts[-1]
+        nl = len(mod._convs)
+        dev = top.device
+        grads: List[Optional[torch.Tensor]] = [None] * (2 * nl + 2)
+        # heads -> masked gradient at the top activation
+        gz = torch.empty_like(top)
+        first = True
+        if g_src is not None:
+            g_src = g_src.contiguous()
+            ops.head_dgrad(g_src, mod.conv1.packed("fwd", mod._g1), gz, top, slope, False, 3, 1)
+            first = False
+            if want_params:
+                grads[2 * nl] = ops.head_wgrad(g_src, top, mod._g1.I, 3, 1)
+        if g_cls is not None:
+            g_cls4 = g_cls.contiguous().view(n, mod.c_dim, 1, 1)
+            ops.head_dgrad(g_cls4, mod.conv2.packed("fwd", mod._g2), gz, top, slope, not first, mod._g2.k, 0)
+            first = False
+            if want_params:
+                grads[2 * nl + 1] = ops.head_wgrad(g_cls4, top, mod._g2.I, mod._g2.k, 0)
+        if first:
+            gz.zero_()
+        gzs = [None] * nl          # gzs[l] = masked gradient at layer l's pre-activation
+        gx = None
+        for li in range(nl - 1, -1, -1):
+            if g_feat is not None and li == mod._n_feat - 1:
+                # gradient arriving at the exposed feature map: mask it and add
+                gf = ops.nchw_to_nhwc(g_feat.contiguous(), acts[li + 1].shape[3])
+                L.check(L.load().fcd_lrelu_bwd(L.ptr(gf), L.ptr(acts[li + 1]), L.ptr(gf), gf.numel(), slope,
+                                               L.stream()), "lrelu_bwd")
+                gz = gz + gf
+            gzs[li] = gz
+            g = mod._geoms[li]
+            a_in = acts[li]
+            if want_params:
+                wd = g.wgrad_desc(n, a_in.shape[1], a_in.shape[2], precision=prec)
+                grads[2 * li] = ops.conv_wgrad(wd, gz, a_in)
+                bs = ops.colsum(gz.numel() // gz.shape[3], gz, gz.shape[3])
+                grads[2 * li + 1] = bs if gz.shape[3] == g.O else bs[: g.O].contiguous()
+            if li == 0:
+                if want_x:
+                    d = g.adj_desc(n, gz.shape[1], gz.shape[2], precision=prec)
+                    g0 = ops.conv_gather(d, gz, mod._convs[0].packed("adj", g))
+                    gx = ops.nhwc_to_nchw(g0, mod.num_channels)
+                break
+            d = g.adj_desc(n, gz.shape[1], gz.shape[2], precision=prec, mask_slope=slope)
+            gz = ops.conv_gather(d, gz, mod._convs[li].packed("adj", g), mask=a_in)
+        ctx.mod, ctx.acts, ctx.prec, ctx.gzs = mod, acts, prec, gzs
+        ctx.g_src, ctx.g_cls = g_src, g_cls
+        ctx.set_materialize_grads(False)
+        if gx is None:
+            gx = torch.zeros((n, mod.num_channels) + tuple(acts[0].shape[1:3]), device=dev)
+        return (gx,) + tuple(grads)
+
+    @staticmethod
+    def backward(ctx, gg_x, *gg_params):
+        """Backward-of-backward: only d(dx)/dW is supported (what the gradient penalty needs)."""
+        if any(t is not None for t in gg_params):
+            raise NotImplementedError("differentiating through D's parameter gradients is not supported")
+        mod, acts, prec, gzs = ctx.mod, ctx.acts, ctx.prec, ctx.gzs
+        nl = len(mod._convs)
+        # inputs: mod, acts, prec, want_x, want_params, g_src, g_cls, g_feat, *params
+        needs = ctx.needs_input_grad[8:]
+        out: List[Optional[torch.Tensor]] = [None] * len(needs)
+        if gg_x is None:
+            return (None,) * 8 + tuple(out)
+        n = acts[0].shape[0]
+        slope = mod.slope
+        u = ops.nchw_to_nhwc(gg_x.contiguous(), mod._geoms[0].IP)
+        for li in range(nl):
+            g = mod._geoms[li]
+            if needs[2 * li]:
+                wd = g.wgrad_desc(n, u.shape[1], u.shape[2], precision=prec)
+                out[2 * li] = ops.conv_wgrad(wd, gzs[li], u)
+            if needs[2 * li + 1]:
+                out[2 * li + 1] = torch.zeros_like(mod._convs[li].bias)
+            d = g.fwd_desc(n, u.shape[1], u.shape[2], precision=prec, mask_slope=slope)
+            u = ops.conv_gather(d, u, mod._convs[li].packed("fwd", g), mask=acts[li + 1])
+        if needs[2 * nl] and ctx.g_src is not None:
+            out[2 * nl] = ops.head_wgrad(ctx.g_src, u, mod._g1.I, 3, 1)
+        if needs[2 * nl + 1] and ctx.g_cls is not None:
+            out[2 * nl + 1] = ops.head_wgrad(ctx.g_cls.contiguous().view(n, mod.c_dim, 1, 1), u, mod._g2.I, mod._g2.k, 0)
+        # d/d g_src, d/d g_cls (linear) are not needed by the GP: grad_outputs is a constant
+        ctx.gzs = None
+        return (None,) * 8 + tuple(out)

@@ -1,0 +1,288 @@
+"""StarGAN-style Generator of the Fixed-Point GAN on the HIP kernels.
+
+Drop-in for the reference ``Generator`` (``models/fixed_point_gan.py:37-84``,
+``ResidualBlock`` ``:22-34``): same constructor, same ``forward(x, c)``, same
+state_dict keys and shapes (``main.0.weight`` ... ``main.{9+r}.main.{0,3}.weight``,
+``main.{9+r}.main.{1,4}.{weight,bias,running_mean,running_var,num_batches_tracked}``),
+so a reference checkpoint loads unchanged.
+
+The whole network is ONE autograd node: forward runs the chain of HIP launches
+(implicit-GEMM convs on MFMA, fused InstanceNorm+ReLU(+residual), fused
+tanh/invalid-mask epilogue) and keeps the per-layer tensors; backward runs the
+hand-written reverse chain (InstanceNorm backward, data gradients as adjoint
+convolutions, weight gradients as split-K GEMMs).  Activations inside are NHWC.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import ops
+from .ops import ConvGeom
+
+
+def _act_slope(activation: str) -> float:
+    if activation == "relu":
+        return 0.0
+    if activation == "lrelu":
+        return ops.LRELU_SLOPE
+    # silu / mish (fixed_point_gan.py:13-16) are outside the hot path
+    raise NotImplementedError(f"activation {activation!r} has no HIP kernel")
+
+
+class ConvParams(nn.Module):
+    """Holds a conv / transposed-conv weight (and bias); never called directly."""
+
+    def __init__(self, shape, fan_in: int, bias: bool = False):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(*shape))
+        self.bias = nn.Parameter(torch.empty(shape[0])) if bias else None
+        self.fan_in = fan_in
+        self.reset_parameters()
+        self._packed = {}
+
+    def reset_parameters(self):
+        # torch's default conv init: kaiming_uniform(a=sqrt(5)) == U(+-1/sqrt(fan_in))
+        bound = 1.0 / math.sqrt(self.fan_in)
+        with torch.no_grad():
+            self.weight.uniform_(-bound, bound)
+            if self.bias is not None:
+                self.bias.uniform_(-bound, bound)
+
+    def packed(self, kind: str, geom: ConvGeom) -> torch.Tensor:
+        """Operand layout for the gather kernel, rebuilt when the parameter changed."""
+        w = self.weight
+        key = (w.data_ptr(), w._version, str(w.device))
+        hit = self._packed.get(kind)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        with torch.no_grad():
+            wd = w.detach().contiguous()
+            t = ops.pack_weight_fwd(wd, geom) if kind == "fwd" else ops.pack_weight_adj(wd, geom)
+        self._packed[kind] = (key, t)
+        return t
+
+
+class NormParams(nn.Module):
+    """InstanceNorm2d(affine=True[, track_running_stats=True]) parameters and buffers."""
+
+    def __init__(self, ch: int, track: bool):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(ch))
+        self.bias = nn.Parameter(torch.zeros(ch))
+        self.track = track
+        if track:
+            self.register_buffer("running_mean", torch.zeros(ch))
+            self.register_buffer("running_var", torch.ones(ch))
+            self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+
+class _Slot(nn.Module):
+    """Parameter-free placeholder that keeps the reference's Sequential indices."""
+
+
+class ResidualBlock(nn.Module):
+    def __init__(self, dim_in: int, dim_out: int):
+        super().__init__()
+        self.main = nn.Sequential(
+            ConvParams((dim_out, dim_in, 3, 3), dim_in * 9),
+            NormParams(dim_out, True),
+            _Slot(),
+            ConvParams((dim_out, dim_out, 3, 3), dim_out * 9),
+            NormParams(dim_out, True))
+
+
+class _Layer:
+    """One conv(+norm) stage of the plan: geometry + parameter holders."""
+
+    def __init__(self, kind, geom, conv, norm, act_slope, res_from=None):
+        self.kind = kind            # "conv" (eq-conv forward) or "convT" (its adjoint)
+        self.geom = geom
+        self.conv = conv
+        self.norm = norm
+        self.act_slope = act_slope  # activation after the norm (1.0 = none)
+        self.res_from = res_from    # index into the saved activations for the residual add
+
+
+class Generator(nn.Module):
+    """Generator network (HIP).  Reference: ``models/fixed_point_gan.py:37-84``."""
+
+    def __init__(self, conv_dim=64, c_dim=5, repeat_num=6, num_channels=3, activation="relu"):
+        super().__init__()
+        slope = _act_slope(activation)
+        self.conv_dim, self.c_dim, self.repeat_num = conv_dim, c_dim, repeat_num
+        self.num_channels, self.activation = num_channels, activation
+        self.precision = L.PREC_F32
+        cin = num_channels + c_dim
+        mods: List[nn.Module] = []
+        plan: List[_Layer] = []
+
+        def add(kind, geom, conv, norm, act):
+            plan.append(_Layer(kind, geom, conv, norm, act))
+
+        c0 = ConvParams((conv_dim, cin, 7, 7), cin * 49)
+        n0 = NormParams(conv_dim, False)
+        mods += [c0, n0, _Slot()]
+        add("conv", ConvGeom(conv_dim, cin, 7, 1, 3), c0, n0, slope)
+        d = conv_dim
+        for _ in range(2):
+            cv = ConvParams((d * 2, d, 4, 4), d * 16)
+            nm = NormParams(d * 2, False)
+            mods += [cv, nm, _Slot()]
+            add("conv", ConvGeom(d * 2, d, 4, 2, 1), cv, nm, slope)
+            d *= 2
+        for _ in range(repeat_num):
+            blk = ResidualBlock(d, d)
+            mods.append(blk)
+            plan.append(_Layer("conv", ConvGeom(d, d, 3, 1, 1), blk.main[0], blk.main[1], slope))
+            plan.append(_Layer("conv", ConvGeom(d, d, 3, 1, 1), blk.main[3], blk.main[4], 1.0, res_from=-2))
+        for _ in range(2):
+            # ConvTranspose2d(d, d/2, 4, 2, 1): weight [d][d/2][4][4]; torch's fan_in is dim 1 * k*k
+            cv = ConvParams((d, d // 2, 4, 4), (d // 2) * 16)
+            nm = NormParams(d // 2, False)
+            mods += [cv, nm, _Slot()]
+            add("convT", ConvGeom(d, d // 2, 4, 2, 1), cv, nm, slope)
+            d //= 2
+        cl = ConvParams((num_channels, d, 7, 7), d * 49)
+        mods.append(cl)
+        plan.append(_Layer("conv", ConvGeom(num_channels, d, 7, 1, 3), cl, None, 1.0))
+        self.main = nn.Sequential(*mods)
+        self._plan = plan
+
+    # parameters in plan order: (conv.weight, norm.weight, norm.bias)*
+    def _flat_params(self):
+        out = []
+        for ly in self._plan:
+            out.append(ly.conv.weight)
+            if ly.norm is not None:
+                out += [ly.norm.weight, ly.norm.bias]
+        return out
+
+    def forward(self, x, c):
+        if not x.is_cuda:
+            raise RuntimeError("fcd_amd.Generator runs on the MI355X HIP path only; move inputs and module to cuda")
+        x = x.contiguous().float()
+        c = c.contiguous().float().view(x.size(0), -1)
+        return _GeneratorFn.apply(self, x, c, *self._flat_params())
+
+
+class _GeneratorFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mod: Generator, x, c, *params):
+        L.require_gpu_tensor(x, "x")
+        n, ch, h, w = x.shape
+        if ch != mod.num_channels or c.shape[1] != mod.c_dim:
+            raise RuntimeError(f"Generator: expected x with {mod.num_channels} bands and c with {mod.c_dim} labels")
+        prec = mod.precision
+        training = mod.training
+        plan = mod._plan
+        cp = plan[0].geom.IP
+        acts = [ops.g_prologue(x, c, cp)]      # acts[i] = input of layer i
+        saved = []                              # per layer: (z, mean, rstd, use_running)
+        pi = 0
+        for li, ly in enumerate(plan):
+            wt = params[pi]
+            pi += 1
+            a = acts[-1]
+            g = ly.geom
+            if ly.kind == "conv":
+                d = g.fwd_desc(n, a.shape[1], a.shape[2], precision=prec)
+                z = ops.conv_gather(d, a, ly.conv.packed("fwd", g))
+            else:
+                d = g.adj_desc(n, a.shape[1], a.shape[2], precision=prec)
+                z = ops.conv_gather(d, a, ly.conv.packed("adj", g))
+            if ly.norm is None:
+                saved.append((z, None, None, False))
+                acts.append(z)
+                continue
+            gamma, beta = params[pi], params[pi + 1]
+            pi += 2
+            nm = ly.norm
+            use_running = nm.track and not training
+            if use_running:
+                mean, rstd = ops.instnorm_stats_from_running(nm.running_mean, nm.running_var, n)
+            else:
+                mean, rstd, varu = ops.instnorm_stats(z, want_var=nm.track)
+                if nm.track:
+                    ops.instnorm_update_running(nm.running_mean, nm.running_var, mean, varu)
+            res = acts[li + 1 + ly.res_from] if ly.res_from is not None else None
+            y = ops.instnorm_apply(z, mean, rstd, gamma.detach(), beta.detach(), ly.act_slope, residual=res)
+            saved.append((z, mean, rstd, use_running))
+            acts.append(y)
+        x_fake = ops.g_epilogue_fwd(acts[-1], x)
+        ctx.mod = mod
+        ctx.acts = acts
+        ctx.saved_layers = saved
+        ctx.x = x
+        ctx.x_fake = x_fake
+        ctx.prec = prec
+        return x_fake
+
+    @staticmethod
+    def backward(ctx, gout):
+        mod, acts, saved, x, x_fake, prec = ctx.mod, ctx.acts, ctx.saved_layers, ctx.x, ctx.x_fake, ctx.prec
+        plan = mod._plan
+        n = x.shape[0]
+        need_x = ctx.needs_input_grad[1]
+        gout = gout.contiguous()
+        gx = torch.empty_like(x) if need_x else None
+        cp_out = acts[-1].shape[3]
+        g = ops.g_epilogue_bwd(gout, x, x_fake, cp_out, gx)   # grad wrt the last conv output (NHWC)
+        # which params need grads (inputs: mod, x, c, *params)
+        needs = ctx.needs_input_grad[3:]
+        grads: List[Optional[torch.Tensor]] = [None] * len(needs)
+        # index of each layer's first param
+        pidx = []
+        k = 0
+        for ly in plan:
+            pidx.append(k)
+            k += 1 if ly.norm is None else 3
+        pending_res = {}       # activation index -> residual gradient to add
+        for li in range(len(plan) - 1, -1, -1):
+            ly = plan[li]
+            z, mean, rstd, use_running = saved[li]
+            a_in = acts[li]
+            y = acts[li + 1]
+            gm = ly.geom
+            p0 = pidx[li]
+            if ly.norm is not None:
+                if ly.res_from is not None:
+                    pending_res[li + 1 + ly.res_from] = g      # h_out = h_in + IN(..): pass g to h_in too
+                want_aff = needs[p0 + 1] or needs[p0 + 2]
+                dz, dgam, dbet = ops.instnorm_bwd(g, y if ly.res_from is None else z, z, mean, rstd,
+                                                  ly.norm.weight.detach(), ly.act_slope, use_running,
+                                                  want_affine=want_aff)
+                if needs[p0 + 1]:
+                    grads[p0 + 1] = dgam
+                if needs[p0 + 2]:
+                    grads[p0 + 2] = dbet
+            else:
+                dz = g
+            # weight gradient
+            if needs[p0]:
+                if ly.kind == "conv":
+                    wd = gm.wgrad_desc(n, a_in.shape[1], a_in.shape[2], precision=prec)
+                    grads[p0] = ops.conv_wgrad(wd, dz, a_in)
+                else:
+                    wd = gm.wgrad_desc(n, dz.shape[1], dz.shape[2], precision=prec)
+                    grads[p0] = ops.conv_wgrad(wd, a_in, dz)
+            # data gradient
+            if li == 0:
+                if need_x:
+                    d = gm.adj_desc(n, dz.shape[1], dz.shape[2], precision=prec)
+                    g0 = ops.conv_gather(d, dz, ly.conv.packed("adj", gm))
+                    ops.nhwc_to_nchw(g0, x.shape[1], out=gx, accumulate=True)
+                break
+            res = pending_res.pop(li, None)
+            if ly.kind == "conv":
+                d = gm.adj_desc(n, dz.shape[1], dz.shape[2], precision=prec)
+                g = ops.conv_gather(d, dz, ly.conv.packed("adj", gm), residual=res)
+            else:
+                d = gm.fwd_desc(n, dz.shape[1], dz.shape[2], precision=prec)
+                g = ops.conv_gather(d, dz, ly.conv.packed("fwd", gm), residual=res)
+        ctx.acts = ctx.saved_layers = None
+        return (None, gx, None) + tuple(grads)
