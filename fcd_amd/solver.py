@@ -1,0 +1,313 @@
+"""FCD solver on the HIP path: the reference ``FCDSolver`` API without Lightning.
+
+Mirrors ``fcd_solver.py``: ``training_step(batch, batch_idx, optimizer_idx)`` (:272),
+``gradient_penalty`` (:227), ``classification_loss`` (:260), ``configure_optimizers``
+(:181), ``optimizer_step`` gating (:549-564), ``compute_difference_map`` (:802),
+``make_psuedo_masks`` (:729, also exposed as ``generate_masks``) and ``binarize`` (:566).
+What Lightning did around those hooks (toggle_optimizer, closure, backward,
+zero_grad(set_to_none=True)) is ``train_step``.  Every tensor op on the path is a
+launch into libfcd_hip.so; torch supplies memory, streams, autograd bookkeeping
+and the (optional) RCCL process group.
+"""
+from __future__ import annotations
+
+from argparse import Namespace
+from typing import Dict, Iterable, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import losses, ops
+from .discriminator import Discriminator, input_grad_only
+from .generator import Generator
+
+
+def default_config(**over) -> Namespace:
+    """Hot-path defaults of ``fcd_main.py:79-158``."""
+    cfg = dict(c_dim=1, image_size=128, g_conv_dim=64, d_conv_dim=64, g_repeat_num=6, d_repeat_num=6,
+               lambda_cls=1.0, lambda_rec=10.0, lambda_gp=10.0, lambda_id=10.0, lambda_feat=1.0, lambda_vgg=1.0,
+               dataset="L8Biome", batch_size=16, num_iters=200000, num_iters_decay=100000, g_lr=1e-4, d_lr=1e-4,
+               n_critic=5, beta1=0.5, beta2=0.999, act_D="lrelu", act_G="relu", n_feat_layers=4,
+               interm_non_act=False, use_attention=False, use_feats=False, use_vgg=False, init_type="none",
+               num_channels=10, mode="train", precision="fp32", device="cuda")
+    cfg.update(over)
+    return Namespace(**cfg)
+
+
+class FusedAdam(torch.optim.Optimizer):
+    """torch.optim.Adam(lr, betas) semantics (``fcd_solver.py:183,186``) with the HIP update."""
+
+    def __init__(self, params, lr=1e-4, betas=(0.5, 0.999), eps=1e-8):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st["step"] += 1
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                ops.adam_step(p, g, st["exp_avg"], st["exp_avg_sq"], group["lr"], b1, b2, group["eps"], st["step"])
+        return loss
+
+
+class FCDSolver(nn.Module):
+    """Solver for training and testing Fixed-Point GAN for Cloud Detection (HIP path)."""
+
+    def __init__(self, config=None, **over):
+        super().__init__()
+        if config is None:
+            config = default_config(**over)
+        elif isinstance(config, dict):
+            config = Namespace(**{**vars(default_config()), **config})
+        self.config = config
+        for k in ("c_dim", "image_size", "g_conv_dim", "d_conv_dim", "g_repeat_num", "d_repeat_num", "lambda_cls",
+                  "lambda_rec", "lambda_gp", "lambda_id", "num_channels", "g_lr", "d_lr", "n_critic", "beta1", "beta2",
+                  "dataset", "batch_size"):
+            setattr(self, k, getattr(config, k))
+        self.act_G, self.act_D = config.act_G, config.act_D
+        self.n_feature_layers = config.n_feat_layers
+        if getattr(config, "use_feats", False) or getattr(config, "use_vgg", False):
+            raise NotImplementedError("use_feats / use_vgg are outside the HIP hot path (SURVEY section 2 row 10)")
+        self.threshold = 0.027                      # fcd_solver.py:79
+        self.global_step = 0
+        self.loss_dict: Dict[str, torch.Tensor] = {}
+        self.alpha_override: Optional[torch.Tensor] = None   # inject alpha (fcd_solver.py:296) for parity tests
+        self.grad_sync = None                       # parallel.GradSync when data-parallel
+        self.build_model()
+        self.set_precision(getattr(config, "precision", "fp32"))
+        self._opts = None
+
+    # ---------------------------------------------------------------- model -------------
+    def build_model(self):
+        """Create a generator and a discriminator (``fcd_solver.py:150-164``, init_type 'none')."""
+        self.G = Generator(self.g_conv_dim, self.c_dim, self.g_repeat_num, self.num_channels, activation=self.act_G)
+        self.D = Discriminator(self.image_size, self.d_conv_dim, self.c_dim, self.d_repeat_num, self.num_channels,
+                               activation=self.act_D, n_feature_layers=self.n_feature_layers)
+
+    def set_precision(self, precision: str):
+        """'fp32': exact-fp32 MFMA; 'bf16': bf16 MFMA operands, fp32 accumulate."""
+        p = {"fp32": L.PREC_F32, "bf16": L.PREC_BF16}[precision]
+        self.G.precision = p
+        self.D.precision = p
+        self.precision = precision
+
+    @property
+    def device(self):
+        return next(self.G.parameters()).device
+
+    def configure_optimizers(self):
+        opt_D = FusedAdam(self.D.parameters(), self.d_lr, (self.beta1, self.beta2))
+        sched_D = torch.optim.lr_scheduler.ReduceLROnPlateau(opt_D, mode="max", patience=10)
+        opt_G = FusedAdam(self.G.parameters(), self.g_lr, (self.beta1, self.beta2))
+        sched_G = torch.optim.lr_scheduler.ReduceLROnPlateau(opt_G, mode="max", patience=10)
+        return ({"optimizer": opt_D, "lr_scheduler": {"scheduler": sched_D, "monitor": "val/F1Score"}},
+                {"optimizer": opt_G, "lr_scheduler": {"scheduler": sched_G, "monitor": "val/F1Score"}})
+
+    def forward(self, x_real, c_org, c_trg, label_org, label_trg):
+        x_fake = self.G(x_real, c_trg)
+        out_src, out_cls, _ = self.D(x_fake)
+        return out_src, out_cls
+
+    # ---------------------------------------------------------------- losses ------------
+    def gradient_penalty(self, y, x):
+        """Compute gradient penalty: (L2_norm(dy/dx) - 1)**2."""
+        weight = torch.ones(y.size(), device=y.device)
+        with input_grad_only():
+            dydx = torch.autograd.grad(outputs=y, inputs=x, grad_outputs=weight, retain_graph=True,
+                                       create_graph=True, only_inputs=True)[0]
+        return losses.gp_loss(dydx.view(dydx.size(0), -1))
+
+    def classification_loss(self, logit, target, dataset="L8Biome"):
+        """Compute binary cross entropy loss."""
+        if dataset in ["L8Biome"]:
+            return losses.bce_logits_mean(logit, target)
+        raise NotImplementedError(dataset)
+
+    def _alpha(self, b, device):
+        if self.alpha_override is not None:
+            return self.alpha_override.to(device).contiguous().float()
+        return torch.rand(b, 1, 1, 1).to(device)
+
+    def training_step(self, batch, batch_idx, optimizer_idx):
+        x_real, c_org, c_trg, label_org, label_trg = batch
+        loss_dict = {}
+        loss = None
+        if optimizer_idx == 0:
+            # ---- train the discriminator (fcd_solver.py:279-308)
+            out_src, out_cls, _ = self.D(x_real)
+            d_loss_real = losses.mean_scaled(out_src, -1.0)
+            d_loss_cls = self.classification_loss(out_cls, label_org, self.dataset)
+
+            x_fake = self.G(x_real, c_trg)
+            out_src, out_cls, _ = self.D(x_fake.detach())
+            d_loss_fake = losses.mean_scaled(out_src, 1.0)
+
+            alpha = self._alpha(x_real.size(0), x_real.device)
+            x_hat = ops.lerp_rows(x_real.detach().contiguous(), x_fake.detach().contiguous(),
+                                  alpha.view(-1)).requires_grad_(True)
+            out_src, _, _ = self.D(x_hat)
+            d_loss_gp = self.gradient_penalty(out_src, x_hat)
+
+            loss = d_loss_real + d_loss_fake + self.lambda_cls * d_loss_cls + self.lambda_gp * d_loss_gp
+            loss_dict["D/loss_real"] = d_loss_real
+            loss_dict["D/loss_fake"] = d_loss_fake
+            loss_dict["D/loss_cls"] = d_loss_cls
+            loss_dict["D/loss_gp"] = d_loss_gp
+        elif optimizer_idx == 1:
+            # ---- train the generator (fcd_solver.py:310-425)
+            if (self.global_step + 1) % self.n_critic == 0:
+                x_fake = self.G(x_real, c_trg)
+                out_src, out_cls, _ = self.D(x_fake)
+                g_loss_fake = losses.mean_scaled(out_src, -1.0)
+                g_loss_cls = self.classification_loss(out_cls, label_trg, self.dataset)
+
+                x_fake_id = self.G(x_real, c_org)
+                out_src_id, out_cls_id, _ = self.D(x_fake_id)
+                g_loss_fake_id = losses.mean_scaled(out_src_id, -1.0)
+                g_loss_cls_id = self.classification_loss(out_cls_id, label_org, self.dataset)
+                g_loss_id = losses.l1_mean(x_real, x_fake_id)
+
+                x_reconst = self.G(x_fake, c_org)
+                g_loss_rec = losses.l1_mean(x_real, x_reconst)
+
+                x_reconst_id = self.G(x_fake_id, c_org)
+                _ = self.D(x_reconst_id)    # reference :358 (outputs feed only the feature-matching loss)
+                g_loss_rec_id = losses.l1_mean(x_real, x_reconst_id)
+
+                g_loss_same = (g_loss_fake_id + self.lambda_rec * g_loss_rec_id + self.lambda_cls * g_loss_cls_id
+                               + self.lambda_id * g_loss_id)
+                loss = g_loss_fake + self.lambda_rec * g_loss_rec + self.lambda_cls * g_loss_cls + g_loss_same
+                loss_dict["G/loss_fake"] = g_loss_fake
+                loss_dict["G/loss_rec"] = g_loss_rec
+                loss_dict["G/loss_cls"] = g_loss_cls
+                loss_dict["G/loss_fake_id"] = g_loss_fake_id
+                loss_dict["G/loss_rec_id"] = g_loss_rec_id
+                loss_dict["G/loss_cls_id"] = g_loss_cls_id
+                loss_dict["G/loss_id"] = g_loss_id
+        self.loss_dict.update({k: v.detach() for k, v in loss_dict.items()})
+        return loss
+
+    # ---------------------------------------------------------------- training loop body -
+    def optimizers(self):
+        if self._opts is None:
+            od, og = self.configure_optimizers()
+            self._opts = (od["optimizer"], og["optimizer"])
+        return self._opts
+
+    def _run_optimizer(self, batch, batch_idx, optimizer_idx, step: bool):
+        """What Lightning does per optimizer: toggle, closure (training_step + backward), step, zero_grad."""
+        opt = self.optimizers()[optimizer_idx]
+        mine, other = (self.D, self.G) if optimizer_idx == 0 else (self.G, self.D)
+        other.requires_grad_(False)
+        mine.requires_grad_(True)
+        try:
+            loss = self.training_step(batch, batch_idx, optimizer_idx)
+            if loss is not None:
+                loss.backward()
+                if self.grad_sync is not None:
+                    self.grad_sync.allreduce([p for p in mine.parameters() if p.grad is not None])
+                if step:
+                    opt.step()
+            opt.zero_grad(set_to_none=True)
+        finally:
+            other.requires_grad_(True)
+        return loss
+
+    def train_step(self, batch, batch_idx: int = 0, force_g: bool = False):
+        """One D update and (every ``n_critic`` steps, or when ``force_g``) one G update:
+        ``optimizer_step`` of ``fcd_solver.py:549-561``."""
+        batch = tuple(t.to(self.device) for t in batch)
+        if force_g:
+            self.global_step = self.n_critic - 1 + (self.global_step // self.n_critic) * self.n_critic
+        d_loss = self._run_optimizer(batch, batch_idx, 0, True)
+        g_loss = self._run_optimizer(batch, batch_idx, 1, (self.global_step + 1) % self.n_critic == 0)
+        self.global_step += 1
+        return d_loss, g_loss
+
+    # ---------------------------------------------------------------- inference ---------
+    @torch.no_grad()
+    def compute_difference_map(self, inputs):
+        """mean_c(|G(x, 0) - x| / 2): translate to "no clouds" and compare (``fcd_solver.py:802-807``)."""
+        c_trg = torch.zeros(inputs.shape[0], self.c_dim, device=inputs.device)
+        x_fake = self.G(inputs, c_trg)
+        diff, _ = ops.diffmap_threshold(x_fake, inputs.contiguous().float(), None)
+        return diff
+
+    @torch.no_grad()
+    def difference_and_mask(self, inputs, threshold: float):
+        """Fused difference map + ``> threshold`` (fp32 compare, uint8), ``fcd_solver.py:761-762``."""
+        c_trg = torch.zeros(inputs.shape[0], self.c_dim, device=inputs.device)
+        x_fake = self.G(inputs, c_trg)
+        return ops.diffmap_threshold(x_fake, inputs.contiguous().float(), float(threshold))
+
+    @torch.no_grad()
+    def make_psuedo_masks(self, threshold=None, dataset: Optional[Iterable] = None, save=False, h5=True):
+        """Pseudo masks for an iterable of samples ``{'image': (B,C,H,W)[, 'mask': (B,H,W)]}``.
+
+        Same semantics as the reference (``fcd_solver.py:729-799``): ``G.eval()``, difference map,
+        ``> threshold`` -> uint8, ``+1``, invalid (``mask == 0``) -> 0.  Returns the stacked uint8
+        masks; writing HDF5/tiff files is the caller's business (storage is out of the hot path)."""
+        if dataset is None:
+            raise ValueError("make_psuedo_masks needs an iterable of samples")
+        if threshold is None:
+            threshold = self.find_best_threshold(dataset=dataset)[0]
+        self.G.eval()
+        out = []
+        for sample in dataset:
+            inputs = sample["image"].to(self.device)
+            _, m = self.difference_and_mask(inputs, threshold)
+            m = m + 1
+            if "mask" in sample:
+                valid = sample["mask"].to(self.device) > 0
+                m[~valid] = 0
+            out.append(m.cpu())
+        return torch.cat(out).numpy()
+
+    generate_masks = make_psuedo_masks
+
+    @torch.no_grad()
+    def find_best_threshold(self, n_thresholds=30, dataset: Optional[Iterable] = None):
+        """Threshold sweep maximising macro F1 on samples with ground-truth masks
+        (``fcd_solver.py:680-725``, first local maximum like the reference's early ``break``)."""
+        self.G.eval()
+        preds, targets = [], []
+        for sample in dataset:
+            d = self.compute_difference_map(sample["image"].to(self.device)).cpu().numpy().astype(np.float32)
+            t = sample["mask"].numpy()
+            valid = t > 0
+            preds.append(d[valid])
+            targets.append(t[valid] - 1)
+        preds, targets = np.concatenate(preds), np.concatenate(targets)
+        best_f1, best_thr = None, None
+        for thr in np.linspace(preds.min(), preds.max(), n_thresholds):
+            p = (preds > thr).astype(np.uint8)
+            f1s = []
+            for cls in (0, 1):
+                tp = float(np.sum((p == cls) & (targets == cls)))
+                fp = float(np.sum((p == cls) & (targets != cls)))
+                fn = float(np.sum((p != cls) & (targets == cls)))
+                f1s.append(2 * tp / max(2 * tp + fp + fn, 1e-12))
+            f1 = float(np.mean(f1s))
+            if best_f1 is None or f1 >= best_f1:
+                best_f1, best_thr = f1, float(thr)
+            else:
+                break
+        return best_thr, dataset
+
+    def binarize(self, difference, threshold=0.2):
+        """numpy ``>`` in the array's own dtype (``fcd_solver.py:566-567``)."""
+        return (difference > threshold).astype(np.uint8)
