@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""FCD train images/sec: one full G+D step (D update with gradient penalty + G update, both
+Adam steps) on synthetic 128x128 10-band patches, batch 16 per GPU.
+
+    python bench.py --gpus N --steps K --warmup W [--precision fp32|bf16]
+
+One rank per GPU (torch.distributed / RCCL when N > 1, launched by torch.distributed.run).
+Rank 0 prints ONE JSON line; `value` is whole-job images/sec with inputs resident in HBM.
+Beside it: `roofline` of the dominant kernel (the 256->256 3x3 residual-block convolution,
+MFMA-bound) timed live with HIP events on the launch stream, and `cpu_baseline`: the CPU
+oracle (a port of the reference's step) timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BASE = dict(batch=16, size=128, bands=10, c_dim=1, conv_dim=64, g_repeat=6, d_repeat=6)
+# algorithmic work per image of one G+D step: 12+1 G passes, 15 D passes
+GFLOP_PER_IMG = 293.72
+PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0}   # MI355X_MICROARCH.md dense MFMA peaks
+
+
+def dominant_kernel_roofline(precision, dev, iters=20):
+    """The hottest kernel: 3x3 s1 256->256 conv at 32x32, B=16 (forward form; dgrad runs the
+    same kernel with flipped taps).  FLOPs per launch = 2*B*Cin*Cout*9*H*W."""
+    from fcd_amd import _lib as L, ops
+    g = ops.ConvGeom(256, 256, 3, 1, 1)
+    n, h, w = BASE["batch"], 32, 32
+    x = torch.randn(n, h, w, 256, device=dev)
+    wt = torch.randn(256, 256, 3, 3, device=dev) / 48.0
+    wf = ops.pack_weight_fwd(wt, g)
+    prec = L.PREC_BF16 if precision == "bf16" else L.PREC_F32
+    d = g.fwd_desc(n, h, w, precision=prec)
+    out = ops.conv_gather(d, x, wf)
+    for _ in range(3):
+        ops.conv_gather(d, x, wf, out=out)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        ops.conv_gather(d, x, wf, out=out)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    flops = 2.0 * n * 256 * 256 * 9 * h * w
+    achieved = flops / (ms * 1e-3) / 1e12
+    peak = PEAK_TFLOPS[precision]
+    return {"bound": "mfma", "kernel": "conv_gather_kernel<128,128> 3x3 256->256 @32x32 B16",
+            "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+            "us_per_launch": round(ms * 1e3, 2), "gflop_per_launch": round(flops / 1e9, 3), "traffic": None}
+
+
+def cpu_baseline():
+    """CPU oracle (port of the reference step: oracle/fcd_oracle.py) on the host cores: one
+    G+D step (D-step + G-step + both Adam updates) at B=16, fp32."""
+    from oracle import fcd_oracle as O
+    cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1)))
+    torch.set_num_threads(cores)
+    gs = O.synth_generator_state(BASE["conv_dim"], BASE["c_dim"], BASE["g_repeat"], BASE["bands"])
+    ds = O.synth_discriminator_state(BASE["size"], BASE["conv_dim"], BASE["c_dim"], BASE["d_repeat"], BASE["bands"])
+    batch, alpha = O.synth_batch(BASE["batch"], BASE["size"], BASE["bands"])
+    t0 = time.perf_counter()
+    _, _, dg = O.d_step(gs, ds, batch, alpha, new_stats={})
+    for k, g in dg.items():
+        ds[k], _, _ = O.adam_update(ds[k], g, torch.zeros_like(g), torch.zeros_like(g), 1)
+    _, _, gg = O.g_step(gs, ds, batch, new_stats={})
+    for k, g in gg.items():
+        gs[k], _, _ = O.adam_update(gs[k], g, torch.zeros_like(g), torch.zeros_like(g), 1)
+    dt = time.perf_counter() - t0
+    return {"value": round(BASE["batch"] / dt, 3), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": "1 full G+D step (D-step+GP, G-step, Adam x2), B=16, 128x128x10, fp32, no warm-up",
+            "seconds": round(dt, 2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--precision", default=os.environ.get("FCD_PRECISION", "fp32"), choices=["fp32", "bf16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the FCD hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from fcd_amd import FCDSolver, _lib
+    from fcd_amd.parallel import GradSync
+    from fcd_amd.synth import synth_batch
+    _lib.check(_lib.load().fcd_init(local_rank), "fcd_init")
+
+    torch.manual_seed(8888)
+    solver = FCDSolver(None, batch_size=BASE["batch"], precision=args.precision).to(dev)
+    if world > 1:
+        solver.grad_sync = GradSync()
+        solver.grad_sync.broadcast_params([solver.G, solver.D])
+    # per-rank batch (weak scaling: 16 images per GPU), resident in HBM before timing
+    batch, _ = synth_batch(BASE["batch"], BASE["size"], BASE["bands"], seed=8888 + rank)
+    batch = tuple(t.to(dev) for t in batch)
+
+    def step():
+        solver.train_step(batch, force_g=True)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = BASE["batch"] * world * args.steps / dt
+        res = {"metric": "FCD train images/sec (G+D step, 128x128 multispectral)", "value": round(value, 2),
+               "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32" if args.precision == "fp32" else "bf16",
+               "data": "synthetic (numpy PCG64 uint16 patches -> [-1,1], nodata rectangle; random-init weights)",
+               "config": {"workload": "FCD G+D train step incl. gradient penalty, batch 16/GPU, 128x128x10, "
+                                      "6 res blocks, D x6 (BASELINE.json configs[1])",
+                          "global_batch": BASE["batch"] * world, "parallelism": f"dp{world}",
+                          "precision": args.precision},
+               "step_tflops": round(GFLOP_PER_IMG * BASE["batch"] / (ms * 1e-3) / 1e3, 2)}
+        res["roofline"] = dominant_kernel_roofline(args.precision, dev)
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
