@@ -12,6 +12,7 @@
 // combined in a fixed order by a second kernel, so results are bitwise
 // reproducible run to run.
 #include "fcd_common.h"
+#include <stdlib.h>
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 
@@ -444,6 +445,386 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs p) {
   }
 }
 
+
+// ============================================================================================
+// fp32 path, v2: operand tiles go global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds) into an
+// S-stage ring, S-1 K-tiles ahead of the MFMAs; out-of-image taps and ragged edges are lanes
+// whose buffer offset is out of range, which the hardware turns into zeros in LDS (probed on
+// gfx950: tools/probe_lds_dma_oob.hip).  No staging registers, no ds_write, one barrier per
+// K-tile, counted vmcnt so the prefetch stays in flight across the barrier.
+// ============================================================================================
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+constexpr unsigned OOB = 0x80000000u;   // beyond any tensor this library accepts (< 2 GiB)
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N >= 0 && N <= 16, "vmcnt immediate");
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+  else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  else if constexpr (N == 11) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+  else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if constexpr (N == 13) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+  else if constexpr (N == 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+  else if constexpr (N == 15) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+}
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// Raw buffer descriptor (stride 0, range-checked by byte count) from wave-uniform values.
+__device__ __forceinline__ i32x4 make_rsrc(const void* base, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)base;
+  i32x4 r;
+  r.x = (int)(unsigned)a;
+  r.y = (int)((unsigned)(a >> 32) & 0xFFFFu);
+  r.z = (int)bytes;
+  r.w = 0x00020000;
+  return r;
+}
+
+// One LDS-DMA instruction: every lane moves 16 bytes from rsrc[voff] to LDS[lds_addr + 16*lane];
+// out-of-range lanes write zeros.  Issued from inline asm on purpose: hipcc would otherwise put
+// s_waitcnt vmcnt(0) in front of every LDS read that follows a DMA it knows about, which drains
+// the prefetch ring; completion is tracked by the counted waits in the kernels instead.
+__device__ __forceinline__ void dma16(const i32x4 rsrc, const unsigned voff, const unsigned lds_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dwordx4 %1, %2, 0 offen lds\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(rsrc), "s"(lds_addr)
+      : "memory");
+}
+
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
+  return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)p;
+}
+
+// XCD-aware tile order: workgroups b and b+8 share an XCD (and its L2), so give each XCD a
+// contiguous run of logical tiles (neighbours share activation rows / weight columns).
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7, x = bid & 7, i = bid >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
+template <int BM, int BN, int WM, int WN, int S>
+__global__ __launch_bounds__(256) void conv_gather_dma_kernel(const GatherArgs p, const unsigned in_bytes,
+                                                              const unsigned w_bytes) {
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int AL = BM / 32, BL = BN / 32;     // DMA instructions per wave per K-tile
+  constexpr int STAGE = (BM + BN) * 8;          // float4 chunks per stage
+  static_assert(WM * WN == 4 && S >= 2, "shape");
+
+  __shared__ float4 smem[S * STAGE + BM / 2];   // ring + rowoff (BM longs)
+  long* rowoff = reinterpret_cast<long*>(smem + S * STAGE);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tn = bid % p.tiles_n, tm = bid / p.tiles_n;
+  const int phase = blockIdx.y / p.splitk, ks = blockIdx.y % p.splitk;
+  const int pad_h = p.pad_h[phase], pad_w = p.pad_w[phase];
+  const int ghw = p.GH * p.GW;
+
+  for (int r = tid; r < BM; r += 256) {
+    const int m = tm * BM + r;
+    long off = -1;
+    if (m < p.M) {
+      const int n = m / ghw, rem = m - n * ghw;
+      const int a = rem / p.GW, b = rem - a * p.GW;
+      off = p.splitk > 1 ? (long)m * p.CoutP
+                         : (((long)n * p.OH + a * p.ostride + p.ooff_h[phase]) * p.OW + b * p.ostride +
+                            p.ooff_w[phase]) * p.CoutP;
+    }
+    rowoff[r] = off;
+  }
+
+  const i32x4 rin = make_rsrc(p.in, in_bytes);
+  const i32x4 rw = make_rsrc(p.w + (long)phase * p.w_phase_stride, w_bytes);
+  const unsigned lds0 = lds_addr_of(smem);
+
+  // this lane fills slot (lane&7) of row rl = 8*wave + (lane>>3) (+32 per instruction); the slot
+  // holds chunk kc = slot ^ ((row>>1)&7): the swizzle lives in the SOURCE address.
+  const int rl = 8 * wave + (lane >> 3);
+  const int kc = (lane & 7) ^ ((rl >> 1) & 7);
+  int a_base[AL];          // byte offset of (n, ih0, iw0, 0); may be negative
+  unsigned a_mh[AL], a_mw[AL];
+#pragma unroll
+  for (int i = 0; i < AL; ++i) {
+    const int m = tm * BM + rl + 32 * i;
+    a_base[i] = 0;
+    a_mh[i] = a_mw[i] = 0u;
+    if (m < p.M) {
+      const int n = m / ghw, rem = m - n * ghw;
+      const int a = rem / p.GW, b = rem - a * p.GW;
+      const int ih0 = a * p.istride - pad_h, iw0 = b * p.istride - pad_w;
+      a_base[i] = ((n * p.IH + ih0) * p.IW + iw0) * p.Cin * 4;
+      for (int t = 0; t < p.KH; ++t) a_mh[i] |= (unsigned)(ih0 + t >= 0 && ih0 + t < p.IH) << t;
+      for (int t = 0; t < p.KW; ++t) a_mw[i] |= (unsigned)(iw0 + t >= 0 && iw0 + t < p.IW) << t;
+    }
+  }
+  unsigned b_base[BL];
+#pragma unroll
+  for (int i = 0; i < BL; ++i) {
+    const int co = tn * BN + rl + 32 * i;
+    b_base[i] = co < p.Cout ? (unsigned)(co * p.K * 4) : OOB;
+  }
+
+  const int kt0 = ks * p.ktiles_per_split;
+  const int kt1 = min(p.ktiles, kt0 + p.ktiles_per_split);
+  const int nk = kt1 - kt0;
+
+  // running decomposition of this lane's k = kt*32 + kc*4 into (th, tw, ci)
+  int k = kt0 * 32 + kc * 4;
+  int tap = k / p.Cin, ci = k - tap * p.Cin;
+  int th = tap / p.KW, tw = tap - th * p.KW;
+
+  // Every lane issues exactly AL + BL DMA instructions per K-tile with full EXEC (the counted
+  // vmcnt below relies on it), so validity is folded into the offset with pure ALU selects.
+  // k >= K needs no test: its tap index is >= KH*KW, whose mask bits are zero.
+  auto issue = [&](int stage) {
+    const unsigned tapoff = (unsigned)(((th * p.IW + tw) * p.Cin + ci) * 4);
+    const unsigned la = lds0 + (unsigned)(stage * STAGE + 8 * wave * 8) * 16u;   // A rows 8*wave.. of this stage
+    const unsigned lb = la + BM * 8 * 16u;
+    const unsigned thc = th < 31 ? th : 31;
+#pragma unroll
+    for (int i = 0; i < AL; ++i) {
+      const unsigned okm = 0u - ((a_mh[i] >> thc) & (a_mw[i] >> tw) & 1u);   // all ones when valid
+      const unsigned voff = (((unsigned)a_base[i] + tapoff) & okm) | (OOB & ~okm);
+      dma16(rin, voff, la + i * (32 * 8 * 16));
+    }
+#pragma unroll
+    for (int i = 0; i < BL; ++i) {
+      const unsigned voff = b_base[i] + (unsigned)(k * 4);   // invalid rows stay >= OOB
+      dma16(rw, voff, lb + i * (32 * 8 * 16));
+    }
+    // advance to the next K-tile
+    k += 32;
+    ci += 32;
+    while (ci >= p.Cin) {
+      ci -= p.Cin;
+      if (++tw == p.KW) { tw = 0; ++th; }
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int lr = lane & 31, lh = lane >> 5;
+
+#pragma unroll
+  for (int s = 0; s < S - 1; ++s)
+    if (s < nk) issue(s);
+
+  int stage = 0, nstage = (S - 1) % S;
+  for (int it = 0; it < nk; ++it) {
+    // tiles issued beyond `it` so far: min(nk, it+S-1) - (it+1); keep them in flight
+    if (it + S - 1 <= nk) wait_vmcnt<(AL + BL) * (S - 2)>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (it + S - 1 < nk) issue(nstage);
+    const float4* As = smem + stage * STAGE;
+    const float4* Bs = As + BM * 8;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float4 af[TM], bf[TN];
+      const int c = 2 * j + lh;
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi) {
+        const int r = wm * WTM + mi * 32 + lr;
+        af[mi] = As[r * 8 + (c ^ ((r >> 1) & 7))];
+      }
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni) {
+        const int r = wn * WTN + ni * 32 + lr;
+        bf[ni] = Bs[r * 8 + (c ^ ((r >> 1) & 7))];
+      }
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].x, bf[ni].x, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].y, bf[ni].y, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].z, bf[ni].z, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].w, bf[ni].w, acc[mi][ni], 0, 0, 0);
+        }
+    }
+    stage = stage + 1 == S ? 0 : stage + 1;
+    nstage = nstage + 1 == S ? 0 : nstage + 1;
+  }
+  __syncthreads();   // rowoff visible even when nk == 0
+
+  float* __restrict__ dst = p.splitk > 1 ? p.slab + (long)blockIdx.y * p.M * p.CoutP : p.out;
+#pragma unroll
+  for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) {
+      const int co = tn * BN + wn * WTN + ni * 32 + lr;
+      if (co >= p.CoutP) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * WTM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const long off = rowoff[row];
+        if (off < 0) continue;
+        float v = acc[mi][ni][r];
+        if (p.splitk == 1) v = co < p.Cout ? epilogue_value(v, co, off + co, p) : 0.f;
+        dst[off + co] = v;
+      }
+    }
+}
+
+// Weight gradient, fp32, LDS-DMA ring.  LDS tiles are [32 pixels][BM | BN] floats, unpadded (one
+// DMA instruction of a wave writes 1 KiB = 256/BM consecutive pixel rows).
+template <int BM, int BN, int WM, int WN, int S>
+__global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradArgs p, const unsigned gs_bytes,
+                                                             const unsigned xb_bytes) {
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int AL = BM / 32, BL = BN / 32;
+  constexpr int ARPI = 256 / BM, BRPI = 256 / BN;     // pixel rows per DMA instruction
+  constexpr int STAGE = 32 * (BM + BN);               // floats per stage
+  static_assert(WM * WN == 4 && S >= 2, "shape");
+
+  __shared__ float smem[S * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tn = bid % p.tiles_n, tm = bid / p.tiles_n;
+  const int ks = blockIdx.y;
+
+  const i32x4 rgs = make_rsrc(p.gs, gs_bytes);
+  const i32x4 rxb = make_rsrc(p.xb, xb_bytes);
+  const unsigned lds0 = lds_addr_of(smem);
+
+  const int kt0 = ks * p.ktiles_per_split;
+  const int kt1 = min(p.ktiles, kt0 + p.ktiles_per_split);
+  const int nk = kt1 - kt0;
+
+  // A (gs): lane -> (pixel row within the instruction, 4 columns)
+  const int a_row = lane / (BM / 4), a_col = (lane % (BM / 4)) * 4;
+  const int o0 = tm * BM + a_col;
+  const bool a_colok = o0 < p.OP;
+  int a_px[AL];
+#pragma unroll
+  for (int i = 0; i < AL; ++i) a_px[i] = kt0 * 32 + (i * 4 + wave) * ARPI + a_row;
+
+  // B (xb gathered at this lane's tap): column -> (tap, ci)
+  const int b_row = lane / (BN / 4), b_col = (lane % (BN / 4)) * 4;
+  const int nd = tn * BN + b_col;
+  const bool b_colok = nd < p.ND;
+  const int tap = nd / p.IP, ci = nd - tap * p.IP;
+  const int th = tap / p.KW, tw = tap - th * p.KW;
+  const int ghw = p.GH * p.GW;
+  int b_px[BL], b_n[BL], b_a[BL], b_b[BL];
+#pragma unroll
+  for (int i = 0; i < BL; ++i) {
+    b_px[i] = kt0 * 32 + (i * 4 + wave) * BRPI + b_row;
+    b_n[i] = b_px[i] / ghw;
+    const int rem = b_px[i] - b_n[i] * ghw;
+    b_a[i] = rem / p.GW;
+    b_b[i] = rem - b_a[i] * p.GW;
+  }
+
+  auto issue = [&](int stage) {
+    const unsigned la = lds0 + (unsigned)(stage * STAGE + wave * 256) * 4u;
+    const unsigned lb = la + 32 * BM * 4u;
+#pragma unroll
+    for (int i = 0; i < AL; ++i) {
+      const unsigned okm = 0u - (unsigned)(a_colok & (a_px[i] < p.P));
+      const unsigned voff = ((unsigned)((a_px[i] * p.OP + o0) * 4) & okm) | (OOB & ~okm);
+      dma16(rgs, voff, la + i * 4096);
+      a_px[i] += 32;
+    }
+#pragma unroll
+    for (int i = 0; i < BL; ++i) {
+      const int ih = b_a[i] * p.stride - p.pad + th, iw = b_b[i] * p.stride - p.pad + tw;
+      const unsigned okm = 0u - (unsigned)(b_colok & (b_px[i] < p.P) & (ih >= 0) & (ih < p.BH) & (iw >= 0) & (iw < p.BW));
+      const unsigned voff = ((unsigned)((((b_n[i] * p.BH + ih) * p.BW + iw) * p.IP + ci) * 4) & okm) | (OOB & ~okm);
+      dma16(rxb, voff, lb + i * 4096);
+      b_px[i] += 32;
+      b_b[i] += 32;
+      while (b_b[i] >= p.GW) {
+        b_b[i] -= p.GW;
+        if (++b_a[i] == p.GH) { b_a[i] = 0; ++b_n[i]; }
+      }
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int lr = lane & 31, lh = lane >> 5;
+#pragma unroll
+  for (int s = 0; s < S - 1; ++s)
+    if (s < nk) issue(s);
+
+  int stage = 0, nstage = (S - 1) % S;
+  for (int it = 0; it < nk; ++it) {
+    if (it + S - 1 <= nk) wait_vmcnt<(AL + BL) * (S - 2)>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (it + S - 1 < nk) issue(nstage);
+    const float* As = smem + stage * STAGE;
+    const float* Bs = As + 32 * BM;
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      float af[TM], bf[TN];
+      const int kq = 2 * kk + lh;
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi) af[mi] = As[kq * BM + wm * WTM + mi * 32 + lr];
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni) bf[ni] = Bs[kq * BN + wn * WTN + ni * 32 + lr];
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+    }
+    stage = stage + 1 == S ? 0 : stage + 1;
+    nstage = nstage + 1 == S ? 0 : nstage + 1;
+  }
+
+  float* __restrict__ dst = p.slab + (long)ks * p.O * p.ND;
+#pragma unroll
+  for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) {
+      const int col = tn * BN + wn * WTN + ni * 32 + lr;
+      if (col >= p.ND) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = tm * BM + wm * WTM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (o < p.O) dst[(long)o * p.ND + col] = acc[mi][ni][r];
+      }
+    }
+}
+
 __global__ __launch_bounds__(256) void pack_fwd_kernel(const float* __restrict__ w, float* __restrict__ out,
                                                        int O, int I, int IP, int taps) {
   const long total = (long)O * taps * IP;
@@ -484,20 +865,26 @@ __global__ __launch_bounds__(256) void pack_adj_kernel(const float* __restrict__
 template <int BM, int BN, int WM, int WN>
 int launch_gather(const GatherArgs& a, int precision, hipStream_t st) {
   dim3 grid(a.tiles_m * a.tiles_n, a.nphase * a.splitk);
-  if (precision == FCD_PREC_BF16)
+  if (precision == FCD_PREC_BF16) {
     hipLaunchKernelGGL((conv_gather_kernel<BM, BN, WM, WN, true>), grid, dim3(256), 0, st, a);
-  else
-    hipLaunchKernelGGL((conv_gather_kernel<BM, BN, WM, WN, false>), grid, dim3(256), 0, st, a);
+  } else {
+    const unsigned in_bytes = (unsigned)((size_t)a.N * a.IH * a.IW * a.Cin * 4);
+    const unsigned w_bytes = (unsigned)((size_t)a.Cout * a.K * 4);
+    hipLaunchKernelGGL((conv_gather_dma_kernel<BM, BN, WM, WN, 3>), grid, dim3(256), 0, st, a, in_bytes, w_bytes);
+  }
   return fcd_check_launch("conv_gather");
 }
 
 template <int BM, int BN, int WM, int WN>
 int launch_wgrad(const WgradArgs& a, int precision, hipStream_t st) {
   dim3 grid(a.tiles_m * a.tiles_n, a.splitk);
-  if (precision == FCD_PREC_BF16)
+  if (precision == FCD_PREC_BF16) {
     hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN, true>), grid, dim3(256), 0, st, a);
-  else
-    hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN, false>), grid, dim3(256), 0, st, a);
+  } else {
+    const unsigned gs_bytes = (unsigned)((size_t)a.P * a.OP * 4);
+    const unsigned xb_bytes = (unsigned)((size_t)a.N * a.BH * a.BW * a.IP * 4);
+    hipLaunchKernelGGL((conv_wgrad_dma_kernel<BM, BN, WM, WN, 3>), grid, dim3(256), 0, st, a, gs_bytes, xb_bytes);
+  }
   return fcd_check_launch("conv_wgrad");
 }
 
@@ -519,12 +906,18 @@ int validate_conv(const FcdConvDesc* d) {
                 "conv: phase %d writes outside the %dx%d output", ph, d->OH, d->OW);
   }
   FCD_REQUIRE((long)d->N * d->GH * d->GW < (1l << 31), "conv: too many output pixels");
+  FCD_REQUIRE((size_t)d->N * d->IH * d->IW * d->Cin * 4 < (1ull << 31) &&
+                  (size_t)d->nphase * d->Cout * d->KH * d->KW * d->Cin * 4 < (1ull << 31),
+              "conv: operands must be smaller than 2 GiB (32-bit buffer offsets)");
   return FCD_OK;
 }
 
 // tile shape by problem shape (shared by the workspace query and the launch)
 void gather_tile(const FcdConvDesc* d, int& bm, int& bn) {
   const long M = (long)d->N * d->GH * d->GW;
+  if (const char* e = getenv("FCD_TILE")) {   // tuning aid: "128x64" etc.
+    if (sscanf(e, "%dx%d", &bm, &bn) == 2) return;
+  }
   if (d->Cout <= 32) { bm = 128; bn = 32; }
   else if (d->Cout <= 64) { bm = 128; bn = 64; }
   else if (M <= 64) { bm = 64; bn = 128; }
@@ -540,8 +933,10 @@ int resolve_splitk(const FcdConvDesc* d) {
   const long blocks = (long)fcd_cdiv(M, bm) * fcd_cdiv(d->Cout, bn) * d->nphase;
   const int bk = d->precision == FCD_PREC_BF16 ? 64 : 32;
   const int ktiles = fcd_cdiv((long)d->KH * d->KW * d->Cin, bk);
-  if (blocks >= 512) return 1;
-  long sk = (768 + blocks - 1) / blocks;
+  // one workgroup per CU already keeps the MFMA pipes busy (the LDS-DMA ring hides the loads);
+  // split K only when the tile grid leaves most of the 256 CUs idle
+  if (blocks >= 192) return 1;
+  long sk = (256 + blocks - 1) / blocks;
   if (sk > ktiles / 4) sk = ktiles / 4;
   if (sk > 64) sk = 64;
   if (sk < 1) sk = 1;
@@ -596,10 +991,12 @@ extern "C" int fcd_conv_gather(const FcdConvDesc* d, const float* in, const floa
   gather_tile(d, bm, bn);
   a.tiles_m = fcd_cdiv(a.M, bm);
   a.tiles_n = fcd_cdiv(d->Cout, bn);
-  if (bn == 32) rc = launch_gather<128, 32, 4, 1>(a, d->precision, st);
-  else if (bn == 64) rc = launch_gather<128, 64, 2, 2>(a, d->precision, st);
-  else if (bm == 64) rc = launch_gather<64, 128, 2, 2>(a, d->precision, st);
-  else rc = launch_gather<128, 128, 2, 2>(a, d->precision, st);
+  if (bm == 128 && bn == 32) rc = launch_gather<128, 32, 4, 1>(a, d->precision, st);
+  else if (bm == 128 && bn == 64) rc = launch_gather<128, 64, 2, 2>(a, d->precision, st);
+  else if (bm == 64 && bn == 128) rc = launch_gather<64, 128, 2, 2>(a, d->precision, st);
+  else if (bm == 64 && bn == 64) rc = launch_gather<64, 64, 2, 2>(a, d->precision, st);
+  else if (bm == 128 && bn == 128) rc = launch_gather<128, 128, 2, 2>(a, d->precision, st);
+  else { fcd_set_error("conv: no %dx%d tile", bm, bn); return FCD_EINVAL; }
   if (rc) return rc;
   if (a.splitk > 1) {
     const long total = (long)a.nphase * a.M * a.CoutP;
@@ -631,6 +1028,9 @@ static int validate_wgrad(const FcdWgradDesc* d) {
   FCD_REQUIRE(d->KH > 0 && d->KW > 0 && d->stride >= 1 && d->pad >= 0, "wgrad: kernel");
   FCD_REQUIRE(d->splitk >= 0 && d->splitk <= 4096, "wgrad: splitk=%d", d->splitk);
   FCD_REQUIRE((long)d->N * d->GH * d->GW < (1l << 31), "wgrad: too many pixels");
+  FCD_REQUIRE((size_t)d->N * d->GH * d->GW * d->OP * 4 < (1ull << 31) &&
+                  (size_t)d->N * d->BH * d->BW * d->IP * 4 < (1ull << 31),
+              "wgrad: operands must be smaller than 2 GiB (32-bit buffer offsets)");
   return FCD_OK;
 }
 

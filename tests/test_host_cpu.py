@@ -1,0 +1,112 @@
+"""CPU suite: host logic of the HIP path (geometry descriptors, bucketing, state-dict layout),
+the C-ABI library (loads, exports every symbol of include/fcd_hip.h) and loud failure
+without a GPU."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from fcd_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "fcd_hip.h")).read()
+    declared = set(re.findall(r"\b(fcd_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 35
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in fcd_hip.h but not exported"
+    assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
+    loaded = _lib.load()
+    assert loaded.fcd_abi_version() == 1
+
+
+def test_descriptor_structs_match_header_layout():
+    from fcd_amd import _lib
+    assert ctypes.sizeof(_lib.ConvDesc) == 4 * (15 + 16 + 2) + 8
+    assert ctypes.sizeof(_lib.WgradDesc) == 4 * 16
+
+
+def test_workspace_queries_run_without_gpu():
+    from fcd_amd import _lib, ops
+    lib = _lib.load()
+    g = ops.ConvGeom(1024, 512, 4, 2, 1)
+    d = g.fwd_desc(16, 8, 8)                      # D main.0.0: M = 256, needs split-K
+    assert lib.fcd_conv_workspace_bytes(ctypes.byref(d)) > 0
+    d2 = ops.ConvGeom(256, 256, 3, 1, 1).fwd_desc(16, 32, 32)
+    assert lib.fcd_conv_workspace_bytes(ctypes.byref(d2)) == 0
+    w = ops.ConvGeom(256, 256, 3, 1, 1).wgrad_desc(16, 32, 32)
+    assert lib.fcd_wgrad_workspace_bytes(ctypes.byref(w)) >= 256 * 9 * 256 * 4
+    assert lib.fcd_instnorm_workspace_bytes(16, 1024, 256) > 0
+    # bad descriptors are rejected with a message, not a crash
+    bad = g.fwd_desc(16, 8, 8)
+    bad.Cin = 510
+    rc = lib.fcd_conv_gather(ctypes.byref(bad), 16, 16, None, None, None, 16, None, 0, None)
+    assert rc == -1 and b"Cin" in lib.fcd_last_error()
+
+
+def test_conv_geometry():
+    from fcd_amd import ops
+    g = ops.ConvGeom(128, 64, 4, 2, 1)
+    assert g.small_hw(128, 128) == (64, 64) and g.big_hw(64, 64) == (128, 128)
+    d = g.adj_desc(2, 64, 64)
+    assert d.nphase == 4 and d.KH == 2 and d.ostride == 2 and (d.GH, d.GW) == (64, 64)
+    assert [d.pad_h[i] for i in range(4)] == [1, 1, 0, 0] and [d.ooff_w[i] for i in range(4)] == [0, 1, 0, 1]
+    g7 = ops.ConvGeom(64, 11, 7, 1, 3)
+    assert g7.IP == 12 and g7.OP == 64
+    d = g7.adj_desc(2, 20, 24)
+    assert d.nphase == 1 and d.pad_h[0] == 3 and (d.OH, d.OW) == (20, 24) and d.Cout == 11 and d.CoutP == 12
+    w = g7.wgrad_desc(2, 20, 24)
+    assert (w.GH, w.GW, w.O, w.I, w.IP) == (20, 24, 64, 11, 12)
+    with pytest.raises(NotImplementedError):
+        ops.ConvGeom(8, 8, 3, 2, 1).adj_desc(1, 4, 4)
+
+
+def test_state_dict_layout_matches_reference_keys():
+    """Key names/shapes listed in SURVEY.md section 8(b) (reference checkpoints load unchanged)."""
+    from fcd_amd import Discriminator, Generator
+    from oracle import fcd_oracle as O
+    G = Generator(64, 1, 6, 10)
+    ref = O.synth_generator_state(64, 1, 6, 10)
+    sd = G.state_dict()
+    assert set(sd) == set(ref) and all(sd[k].shape == ref[k].shape for k in ref)
+    assert sum(p.numel() for p in G.parameters()) == 8461888
+    D = Discriminator(128, 64, 1, 6, 10)
+    refd = O.synth_discriminator_state(128, 64, 1, 6, 10)
+    sdd = D.state_dict()
+    assert list(sdd) == list(refd) and all(sdd[k].shape == refd[k].shape for k in refd)
+    assert sum(p.numel() for p in D.parameters()) == 44736448
+    G.load_state_dict(ref)
+    D.load_state_dict(refd)
+    # default init: U(+-1/sqrt(fan_in)) like torch's conv default
+    w = Generator(8, 1, 1, 10).main[0].weight
+    assert float(w.abs().max()) <= 1 / (11 * 49) ** 0.5 + 1e-7
+
+
+def test_product_path_fails_loudly_on_cpu():
+    from fcd_amd import Discriminator, Generator
+    G = Generator(8, 1, 1, 10)
+    with pytest.raises(RuntimeError, match="HIP path"):
+        G(torch.zeros(1, 10, 16, 16), torch.zeros(1, 1))
+    with pytest.raises(RuntimeError, match="HIP path"):
+        Discriminator(16, 8, 1, 2, 10)(torch.zeros(1, 10, 16, 16))
+    with pytest.raises(NotImplementedError):
+        Generator(8, 1, 1, 10, activation="mish")
+
+
+def test_no_oracle_import_in_product():
+    pkg = os.path.join(ROOT, "fcd_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert "oracle" not in src.replace("oracle/", ""), fn
+
+
+def test_bucket_plan():
+    from fcd_amd.parallel import plan_buckets
+    assert plan_buckets([10, 10, 10, 50, 5], 25) == [[0, 1], [2], [3], [4]]
+    assert plan_buckets([], 10) == []
+    assert plan_buckets([100], 10) == [[0]]
