@@ -32,6 +32,7 @@ struct GatherArgs {
   int M, ktiles, ktiles_per_split, tiles_m, tiles_n;
   long w_phase_stride;
   float act_slope, mask_slope;
+  int dbg;
 };
 
 __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
@@ -595,24 +596,28 @@ __global__ __launch_bounds__(256) void conv_gather_dma_kernel(const GatherArgs p
 
   // Every lane issues exactly AL + BL DMA instructions per K-tile with full EXEC (the counted
   // vmcnt below relies on it), so validity is folded into the offset with pure ALU selects.
-  // k >= K needs no test: its tap index is >= KH*KW, whose mask bits are zero.
-  auto issue = [&](int stage) {
-    const unsigned tapoff = (unsigned)(((th * p.IW + tw) * p.Cin + ci) * 4);
-    const unsigned la = lds0 + (unsigned)(stage * STAGE + 8 * wave * 8) * 16u;   // A rows 8*wave.. of this stage
-    const unsigned lb = la + BM * 8 * 16u;
-    const unsigned thc = th < 31 ? th : 31;
-#pragma unroll
-    for (int i = 0; i < AL; ++i) {
-      const unsigned okm = 0u - ((a_mh[i] >> thc) & (a_mw[i] >> tw) & 1u);   // all ones when valid
-      const unsigned voff = (((unsigned)a_base[i] + tapoff) & okm) | (OOB & ~okm);
-      dma16(rin, voff, la + i * (32 * 8 * 16));
+  // k >= K needs no test: its tap index is >= KH*KW, whose mask bits are zero.  Tiles past the
+  // end of this block's K range are issued as all-out-of-range dummies (zeros into a free stage).
+  constexpr int ND = AL + BL;
+  unsigned tapoff = 0, thc = 0, live = 0, la = 0, lb = 0;
+  auto issue_prepare = [&](int stage, bool alive) {
+    tapoff = (unsigned)(((th * p.IW + tw) * p.Cin + ci) * 4);
+    thc = th < 31 ? th : 31;
+    live = alive ? 0xFFFFFFFFu : 0u;
+    la = lds0 + (unsigned)(stage * STAGE + 8 * wave * 8) * 16u;   // A rows 8*wave.. of this stage
+    lb = la + BM * 8 * 16u;
+  };
+  auto issue_one = [&](int q) {
+    if (q < AL) {
+      const unsigned okm = (0u - ((a_mh[q] >> thc) & (a_mw[q] >> tw) & 1u)) & live;   // all ones when valid
+      const unsigned voff = (((unsigned)a_base[q] + tapoff) & okm) | (OOB & ~okm);
+      dma16(rin, voff, la + q * (32 * 8 * 16));
+    } else {
+      const unsigned voff = (b_base[q - AL] + (unsigned)(k * 4)) | (OOB & ~live);   // invalid rows stay >= OOB
+      dma16(rw, voff, lb + (q - AL) * (32 * 8 * 16));
     }
-#pragma unroll
-    for (int i = 0; i < BL; ++i) {
-      const unsigned voff = b_base[i] + (unsigned)(k * 4);   // invalid rows stay >= OOB
-      dma16(rw, voff, lb + i * (32 * 8 * 16));
-    }
-    // advance to the next K-tile
+  };
+  auto issue_advance = [&]() {
     k += 32;
     ci += 32;
     while (ci >= p.Cin) {
@@ -632,16 +637,20 @@ __global__ __launch_bounds__(256) void conv_gather_dma_kernel(const GatherArgs p
   const int lr = lane & 31, lh = lane >> 5;
 
 #pragma unroll
-  for (int s = 0; s < S - 1; ++s)
-    if (s < nk) issue(s);
+  for (int s = 0; s < S - 1; ++s) {
+    issue_prepare(s, s < nk);
+#pragma unroll
+    for (int q = 0; q < ND; ++q) issue_one(q);
+    issue_advance();
+  }
 
+  constexpr int G = 4 * TM * TN;          // MFMA groups (4 MFMAs each) per K-tile
   int stage = 0, nstage = (S - 1) % S;
   for (int it = 0; it < nk; ++it) {
-    // tiles issued beyond `it` so far: min(nk, it+S-1) - (it+1); keep them in flight
-    if (it + S - 1 <= nk) wait_vmcnt<(AL + BL) * (S - 2)>();
-    else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    if (it + S - 1 < nk) issue(nstage);
+    // exactly ND*(S-2) younger DMAs are in flight behind tile `it`: keep them flying
+    wait_vmcnt<ND * (S - 2)>();
+    if (!(p.dbg & 2)) __builtin_amdgcn_s_barrier();
+    issue_prepare(nstage, it + S - 1 < nk);
     const float4* As = smem + stage * STAGE;
     const float4* Bs = As + BM * 8;
 #pragma unroll
@@ -664,10 +673,16 @@ __global__ __launch_bounds__(256) void conv_gather_dma_kernel(const GatherArgs p
         for (int ni = 0; ni < TN; ++ni) {
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].x, bf[ni].x, acc[mi][ni], 0, 0, 0);
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].y, bf[ni].y, acc[mi][ni], 0, 0, 0);
+          // the next tile's DMA issue rides in the shadow of the 64-cycle MFMAs
+          const int g = (j * TM + mi) * TN + ni;
+#pragma unroll
+          for (int q = 0; q < ND; ++q)
+            if (q * G / ND == g && !(p.dbg & 1)) issue_one(q);
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].z, bf[ni].z, acc[mi][ni], 0, 0, 0);
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].w, bf[ni].w, acc[mi][ni], 0, 0, 0);
         }
     }
+    issue_advance();
     stage = stage + 1 == S ? 0 : stage + 1;
     nstage = nstage + 1 == S ? 0 : nstage + 1;
   }
@@ -746,20 +761,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradArgs p, 
     b_b[i] = rem - b_a[i] * p.GW;
   }
 
-  auto issue = [&](int stage) {
-    const unsigned la = lds0 + (unsigned)(stage * STAGE + wave * 256) * 4u;
-    const unsigned lb = la + 32 * BM * 4u;
-#pragma unroll
-    for (int i = 0; i < AL; ++i) {
-      const unsigned okm = 0u - (unsigned)(a_colok & (a_px[i] < p.P));
-      const unsigned voff = ((unsigned)((a_px[i] * p.OP + o0) * 4) & okm) | (OOB & ~okm);
-      dma16(rgs, voff, la + i * 4096);
-      a_px[i] += 32;
-    }
-#pragma unroll
-    for (int i = 0; i < BL; ++i) {
+  constexpr int ND = AL + BL;
+  unsigned live = 0, la = 0, lb = 0;
+  auto issue_prepare = [&](int stage, bool alive) {
+    live = alive ? 0xFFFFFFFFu : 0u;
+    la = lds0 + (unsigned)(stage * STAGE + wave * 256) * 4u;
+    lb = la + 32 * BM * 4u;
+  };
+  auto issue_one = [&](int q) {
+    if (q < AL) {
+      const unsigned okm = (0u - (unsigned)(a_colok & (a_px[q] < p.P))) & live;
+      const unsigned voff = ((unsigned)((a_px[q] * p.OP + o0) * 4) & okm) | (OOB & ~okm);
+      dma16(rgs, voff, la + q * 4096);
+      a_px[q] += 32;
+    } else {
+      const int i = q - AL;
       const int ih = b_a[i] * p.stride - p.pad + th, iw = b_b[i] * p.stride - p.pad + tw;
-      const unsigned okm = 0u - (unsigned)(b_colok & (b_px[i] < p.P) & (ih >= 0) & (ih < p.BH) & (iw >= 0) & (iw < p.BW));
+      const unsigned okm = (0u - (unsigned)(b_colok & (b_px[i] < p.P) & (ih >= 0) & (ih < p.BH) & (iw >= 0) & (iw < p.BW))) & live;
       const unsigned voff = ((unsigned)((((b_n[i] * p.BH + ih) * p.BW + iw) * p.IP + ci) * 4) & okm) | (OOB & ~okm);
       dma16(rxb, voff, lb + i * 4096);
       b_px[i] += 32;
@@ -781,15 +799,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradArgs p, 
 
   const int lr = lane & 31, lh = lane >> 5;
 #pragma unroll
-  for (int s = 0; s < S - 1; ++s)
-    if (s < nk) issue(s);
+  for (int s = 0; s < S - 1; ++s) {
+    issue_prepare(s, s < nk);
+#pragma unroll
+    for (int q = 0; q < ND; ++q) issue_one(q);
+  }
 
   int stage = 0, nstage = (S - 1) % S;
   for (int it = 0; it < nk; ++it) {
-    if (it + S - 1 <= nk) wait_vmcnt<(AL + BL) * (S - 2)>();
-    else wait_vmcnt<0>();
+    wait_vmcnt<ND * (S - 2)>();
     __builtin_amdgcn_s_barrier();
-    if (it + S - 1 < nk) issue(nstage);
+    issue_prepare(nstage, it + S - 1 < nk);
     const float* As = smem + stage * STAGE;
     const float* Bs = As + 32 * BM;
 #pragma unroll
@@ -805,6 +825,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradArgs p, 
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni)
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+      // the next tile's DMA issue rides in the shadow of the MFMAs
+#pragma unroll
+      for (int q = 0; q < ND; ++q)
+        if (q * 16 / ND == kk) issue_one(q);
     }
     stage = stage + 1 == S ? 0 : stage + 1;
     nstage = nstage + 1 == S ? 0 : nstage + 1;
@@ -959,6 +983,7 @@ void fill_gather_args(const FcdConvDesc* d, GatherArgs& a) {
   a.splitk = fcd_cdiv(a.ktiles, a.ktiles_per_split);   // no empty splits
   a.w_phase_stride = (long)d->Cout * a.K;
   a.act_slope = d->act_slope; a.mask_slope = d->mask_slope;
+  a.dbg = getenv("FCD_DBG") ? atoi(getenv("FCD_DBG")) : 0;
 }
 
 }  // namespace
