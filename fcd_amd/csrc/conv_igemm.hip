@@ -1038,7 +1038,9 @@ static int resolve_wgrad_splitk(const FcdWgradDesc* d) {
   if (d->splitk > 0) return d->splitk;
   const long tiles = (long)fcd_cdiv(d->O, wgrad_bm(d)) * fcd_cdiv((long)d->KH * d->KW * d->IP, 128);
   const int ktiles = fcd_cdiv((long)d->N * d->GH * d->GW, 32);
-  long sk = (1024 + tiles - 1) / tiles;
+  // aim at one workgroup per CU (the DMA ring keeps a lone workgroup's MFMA pipes fed); more
+  // splits only add slab traffic
+  long sk = (256 + tiles / 2) / tiles;
   if (sk > ktiles / 8) sk = ktiles / 8;
   if (sk > 512) sk = 512;
   if (sk < 1) sk = 1;

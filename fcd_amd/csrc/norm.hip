@@ -27,7 +27,7 @@ ColPlan col_plan(int N, long HW, int C) {
   p.cblocks = (p.c4 + 255) / 256;
   p.rows = 256 / p.c4b;
   if (p.rows < 1) p.rows = 1;
-  long want = 2048 / (N > 0 ? N : 1);
+  long want = 1024 / (N > 0 ? N : 1);
   if (want < 1) want = 1;
   long maxc = (HW + p.rows - 1) / p.rows;   // at least one row per thread
   long chunks = want < maxc ? want : maxc;
@@ -105,40 +105,54 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restric
   }
 }
 
-__global__ __launch_bounds__(256) void stats_finalize_kernel(const double* __restrict__ partial, float* __restrict__ mean,
-                                                             float* __restrict__ rstd, float* __restrict__ var_unb,
-                                                             int N, long HW, int C, int chunks, float eps) {
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (long)N * C) return;
-  const int n = (int)(idx / C), c = (int)(idx % C);
-  double s = 0.0, ss = 0.0;
-  for (int k = 0; k < chunks; ++k) {
-    const double* src = partial + (((long)n * chunks + k) * C + c) * 2;
-    s += src[0];
-    ss += src[1];
-  }
-  const double m = s / (double)HW;
-  double var = ss / (double)HW - m * m;
-  if (var < 0.0) var = 0.0;
-  mean[idx] = (float)m;
-  rstd[idx] = (float)(1.0 / sqrt(var + (double)eps));
-  if (var_unb) var_unb[idx] = (float)(HW > 1 ? var * ((double)HW / (double)(HW - 1)) : var);
-}
+// Second stage of every column reduction: sums the per-chunk partials of 32 channels with 8
+// chunk lanes per channel (fixed order: lane-strided sums, then lanes 0..7), then finishes.
+//   FIN_STATS: mean / rstd / unbiased var per (n, c)
+//   FIN_BWD:   s12[n][c] = (sum g1, sum g1*xhat)
+//   FIN_SUM:   out[c] (+)= sum
+constexpr int FIN_STATS = 0, FIN_BWD = 1, FIN_SUM = 2;
 
-// s12[n][c][2] floats from the partials
-__global__ __launch_bounds__(256) void bwd_finalize_kernel(const double* __restrict__ partial, float* __restrict__ s12,
-                                                           int N, int C, int chunks) {
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (long)N * C) return;
-  const int n = (int)(idx / C), c = (int)(idx % C);
+template <int FIN>
+__global__ __launch_bounds__(256) void finalize_kernel(const double* __restrict__ partial, float* __restrict__ o0,
+                                                       float* __restrict__ o1, float* __restrict__ o2, long HW, int C,
+                                                       int chunks, float eps, int accumulate) {
+  __shared__ double sm[8][32][2];
+  const int n = blockIdx.y;
+  const int cl = threadIdx.x & 31, ln = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
   double s = 0.0, ss = 0.0;
-  for (int k = 0; k < chunks; ++k) {
-    const double* src = partial + (((long)n * chunks + k) * C + c) * 2;
-    s += src[0];
-    ss += src[1];
+  if (c < C) {
+    for (int k = ln; k < chunks; k += 8) {
+      const double* src = partial + (((long)n * chunks + k) * C + c) * 2;
+      s += src[0];
+      if (FIN != FIN_SUM) ss += src[1];
+    }
   }
-  s12[idx * 2 + 0] = (float)s;
-  s12[idx * 2 + 1] = (float)ss;
+  sm[ln][cl][0] = s;
+  sm[ln][cl][1] = ss;
+  __syncthreads();
+  if (ln != 0 || c >= C) return;
+  s = 0.0;
+  ss = 0.0;
+#pragma unroll
+  for (int l = 0; l < 8; ++l) {
+    s += sm[l][cl][0];
+    ss += sm[l][cl][1];
+  }
+  const long idx = (long)n * C + c;
+  if (FIN == FIN_STATS) {
+    const double m = s / (double)HW;
+    double var = ss / (double)HW - m * m;
+    if (var < 0.0) var = 0.0;
+    o0[idx] = (float)m;
+    o1[idx] = (float)(1.0 / sqrt(var + (double)eps));
+    if (o2) o2[idx] = (float)(HW > 1 ? var * ((double)HW / (double)(HW - 1)) : var);
+  } else if (FIN == FIN_BWD) {
+    o0[idx * 2 + 0] = (float)s;
+    o0[idx * 2 + 1] = (float)ss;
+  } else {
+    o0[c] = accumulate ? o0[c] + (float)s : (float)s;
+  }
 }
 
 __global__ __launch_bounds__(256) void affine_grad_kernel(const float* __restrict__ s12, float* __restrict__ dgamma,
@@ -152,15 +166,6 @@ __global__ __launch_bounds__(256) void affine_grad_kernel(const float* __restric
   }
   if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)a : (float)a;
   if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)b : (float)b;
-}
-
-__global__ __launch_bounds__(256) void colsum_finalize_kernel(const double* __restrict__ partial, float* __restrict__ out,
-                                                              int C, int chunks, int accumulate) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0;
-  for (int k = 0; k < chunks; ++k) s += partial[((long)k * C + c) * 2];
-  out[c] = accumulate ? out[c] + (float)s : (float)s;
 }
 
 __global__ __launch_bounds__(256) void in_apply_kernel(const float* __restrict__ z, const float* __restrict__ mean,
@@ -281,8 +286,8 @@ extern "C" int fcd_instnorm_stats(const float* z, float* mean, float* rstd, floa
                      nullptr, nullptr, (double*)workspace, (long)HW, C, pl, 0.f);
   rc = fcd_check_launch("instnorm_stats/partial");
   if (rc) return rc;
-  hipLaunchKernelGGL(stats_finalize_kernel, dim3(fcd_cdiv((long)N * C, 256)), dim3(256), 0, st,
-                     (const double*)workspace, mean, rstd, var_unbiased, N, (long)HW, C, pl.chunks, eps);
+  hipLaunchKernelGGL((finalize_kernel<FIN_STATS>), dim3(fcd_cdiv(C, 32), N), dim3(256), 0, st,
+                     (const double*)workspace, mean, rstd, var_unbiased, (long)HW, C, pl.chunks, eps, 0);
   return fcd_check_launch("instnorm_stats/finalize");
 }
 
@@ -336,7 +341,8 @@ extern "C" int fcd_instnorm_bwd(const float* gy, const float* y, const float* z,
                      partial, (long)HW, C, pl, act_slope);
   rc = fcd_check_launch("instnorm_bwd/partial");
   if (rc) return rc;
-  hipLaunchKernelGGL(bwd_finalize_kernel, dim3(fcd_cdiv((long)N * C, 256)), dim3(256), 0, st, partial, s12, N, C, pl.chunks);
+  hipLaunchKernelGGL((finalize_kernel<FIN_BWD>), dim3(fcd_cdiv(C, 32), N), dim3(256), 0, st, (const double*)partial, s12,
+                     (float*)nullptr, (float*)nullptr, (long)HW, C, pl.chunks, 0.f, 0);
   rc = fcd_check_launch("instnorm_bwd/finalize");
   if (rc) return rc;
   if (dgamma || dbeta) {
@@ -372,7 +378,7 @@ extern "C" int fcd_colsum(const float* x, float* out, int accumulate, size_t row
                      nullptr, (double*)workspace, (long)rows, C, pl, 0.f);
   rc = fcd_check_launch("colsum/partial");
   if (rc) return rc;
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(fcd_cdiv(C, 256)), dim3(256), 0, st, (const double*)workspace, out, C,
-                     pl.chunks, accumulate);
+  hipLaunchKernelGGL((finalize_kernel<FIN_SUM>), dim3(fcd_cdiv(C, 32), 1), dim3(256), 0, st, (const double*)workspace, out,
+                     (float*)nullptr, (float*)nullptr, (long)rows, C, pl.chunks, 0.f, accumulate);
   return fcd_check_launch("colsum/finalize");
 }

@@ -1,0 +1,195 @@
+"""Op-level parity of the HBM-bound HIP kernels (through the C ABI) against torch on CPU."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import relerr
+
+pytestmark = pytest.mark.gpu
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 5, 7), (16, 64, 32, 32), (3, 256, 16, 16), (2, 64, 128, 128)])
+@pytest.mark.parametrize("slope", [0.0, 1.0])
+def test_instnorm_forward_backward(dev, shape, slope):
+    from fcd_amd import ops
+    torch.manual_seed(0)
+    n, c, h, w = shape
+    z = (torch.randn(shape) * 2 + 0.5).requires_grad_(True)
+    gamma = (1 + 0.2 * torch.randn(c)).requires_grad_(True)
+    beta = (0.2 * torch.randn(c)).requires_grad_(True)
+    res = torch.randn(shape)
+    gy = torch.randn(shape)
+    y0 = F.instance_norm(z, None, None, gamma, beta, True, 0.1, 1e-5)
+    y_ref = (F.relu(y0) if slope == 0.0 else y0) + res
+    y_ref.backward(gy)
+    zd = nhwc(z.detach()).to(dev)
+    mean, rstd, varu = ops.instnorm_stats(zd, want_var=True)
+    assert relerr(mean, z.detach().mean((2, 3))) <= 1e-5
+    assert relerr(varu, z.detach().var((2, 3), unbiased=True)) <= 1e-5
+    y = ops.instnorm_apply(zd, mean, rstd, gamma.detach().to(dev), beta.detach().to(dev), slope, residual=nhwc(res).to(dev))
+    assert relerr(y.cpu(), nhwc(y_ref.detach())) <= 1e-5
+    # backward: the activation mask comes from the pre-residual output
+    y_pre = ops.instnorm_apply(zd, mean, rstd, gamma.detach().to(dev), beta.detach().to(dev), slope)
+    dz, dg, db = ops.instnorm_bwd(nhwc(gy).to(dev), y_pre, zd, mean, rstd, gamma.detach().to(dev), slope, False)
+    assert relerr(dz.cpu(), nhwc(z.grad)) <= 2e-5
+    assert relerr(dg, gamma.grad) <= 2e-5 and relerr(db, beta.grad) <= 2e-5
+
+
+def test_instnorm_running_stats_and_eval(dev):
+    from fcd_amd import ops
+    torch.manual_seed(1)
+    n, c, h, w = 4, 16, 8, 8
+    m = torch.nn.InstanceNorm2d(c, affine=True, track_running_stats=True)
+    with torch.no_grad():
+        m.weight.uniform_(0.5, 1.5); m.bias.uniform_(-0.3, 0.3)
+        m.running_mean.uniform_(-0.1, 0.1); m.running_var.uniform_(0.8, 1.2)
+    z = torch.randn(n, c, h, w) * 1.5
+    rm, rv = m.running_mean.clone().to(dev), m.running_var.clone().to(dev)
+    m.train(); m(z)
+    mean, rstd, varu = ops.instnorm_stats(nhwc(z).to(dev), want_var=True)
+    ops.instnorm_update_running(rm, rv, mean, varu)
+    assert relerr(rm, m.running_mean) <= 1e-5 and relerr(rv, m.running_var) <= 1e-5
+    m.eval()
+    ref = m(z)
+    mean, rstd = ops.instnorm_stats_from_running(rm, rv, n)
+    y = ops.instnorm_apply(nhwc(z).to(dev), mean, rstd, m.weight.detach().to(dev), m.bias.detach().to(dev), 1.0)
+    assert relerr(y.cpu(), nhwc(ref.detach())) <= 1e-5
+
+
+@pytest.mark.parametrize("rows,c", [(64, 2048), (65536, 64), (100, 12), (4096, 256)])
+def test_colsum(dev, rows, c):
+    from fcd_amd import ops
+    torch.manual_seed(2)
+    x = torch.randn(rows, c)
+    out = ops.colsum(rows, x.to(dev), c)
+    assert relerr(out, x.double().sum(0)) <= 1e-6
+    out2 = ops.colsum(rows, x.to(dev), c, out=out.clone(), accumulate=True)
+    assert relerr(out2, 2 * x.double().sum(0)) <= 1e-6
+
+
+@pytest.mark.parametrize("o,k,pad", [(1, 3, 1), (1, 2, 0), (5, 2, 0)])
+def test_discriminator_heads(dev, o, k, pad):
+    from fcd_amd import ops
+    torch.manual_seed(3)
+    n, i, h, w = 4, 64, 2, 2
+    x = torch.randn(n, i, h, w, requires_grad=True)
+    wt = (torch.randn(o, i, k, k) / (i * k * k) ** 0.5).requires_grad_(True)
+    y = F.conv2d(x, wt, None, 1, pad)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    g = ops.ConvGeom(o, i, k, 1, pad)
+    wp = ops.pack_weight_fwd(wt.detach().to(dev), g)
+    xd = nhwc(x.detach()).to(dev)
+    out = ops.head_fwd(xd, wp, o, k, pad)
+    assert relerr(out, y) <= 1e-5
+    mask = torch.randn(n, i, h, w)
+    din = torch.empty_like(xd)
+    ops.head_dgrad(gy.to(dev), wp, din, nhwc(mask).to(dev), 0.01, False, k, pad)
+    assert relerr(din.cpu(), nhwc(x.grad * torch.where(mask > 0, 1.0, 0.01))) <= 1e-5
+    dw = ops.head_wgrad(gy.to(dev), xd, i, k, pad)
+    assert relerr(dw, wt.grad) <= 1e-5
+
+
+def test_losses_forward_backward(dev):
+    from fcd_amd import losses
+    torch.manual_seed(4)
+    a = torch.randn(3, 10, 16, 16)
+    b = torch.randn(3, 10, 16, 16)
+    b[0, 0, 0, :4] = a[0, 0, 0, :4]            # exact ties: sign(0) = 0 like torch
+    ad, bd = a.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    ar, br = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    (3.0 * losses.l1_mean(ad, bd)).backward()
+    (3.0 * torch.mean(torch.abs(ar - br))).backward()
+    assert relerr(ad.grad, ar.grad) <= 1e-6 and relerr(bd.grad, br.grad) <= 1e-6
+    assert abs(float(losses.l1_mean(ad, bd)) - float(torch.mean(torch.abs(a - b)))) <= 1e-6
+
+    x = torch.randn(16, 1) * 3
+    t = (torch.rand(16, 1) < 0.5).float()
+    xd, xr = x.to(dev).requires_grad_(True), x.clone().requires_grad_(True)
+    l = losses.bce_logits_mean(xd, t.to(dev)); l.backward()
+    lr = F.binary_cross_entropy_with_logits(xr, t); lr.backward()
+    assert abs(float(l) - float(lr)) <= 1e-6 and relerr(xd.grad, xr.grad) <= 1e-6
+
+    s = torch.randn(16, 1, 2, 2)
+    sd, sr = s.to(dev).requires_grad_(True), s.clone().requires_grad_(True)
+    l = losses.mean_scaled(sd, -1.0); (2 * l).backward()
+    lr = -torch.mean(sr); (2 * lr).backward()
+    assert abs(float(l) - float(lr)) <= 1e-6 and relerr(sd.grad, sr.grad) <= 1e-6
+
+    g = torch.randn(4, 1000)
+    gd, gr = g.to(dev).requires_grad_(True), g.clone().requires_grad_(True)
+    l = losses.gp_loss(gd); l.backward()
+    lr = torch.mean((torch.sqrt(torch.sum(gr ** 2, dim=1)) - 1) ** 2); lr.backward()
+    assert abs(float(l) - float(lr)) <= 1e-5 * abs(float(lr)) and relerr(gd.grad, gr.grad) <= 1e-5
+
+
+def test_adam_matches_torch(dev):
+    from fcd_amd import FusedAdam
+    torch.manual_seed(5)
+    p0 = torch.randn(1000, 7)
+    pr = torch.nn.Parameter(p0.clone())
+    pd = torch.nn.Parameter(p0.clone().to(dev))
+    o_ref = torch.optim.Adam([pr], 1e-4, (0.5, 0.999))
+    o_hip = FusedAdam([pd], 1e-4, (0.5, 0.999))
+    for _ in range(3):
+        g = torch.randn_like(p0)
+        pr.grad = g.clone(); pd.grad = g.clone().to(dev)
+        o_ref.step(); o_hip.step()
+    assert relerr(pd, pr) <= 1e-6
+    assert relerr(pd.detach().cpu() - p0, pr.detach() - p0) <= 1e-4
+
+
+def test_layout_and_epilogue(dev):
+    from fcd_amd import ops
+    torch.manual_seed(6)
+    x = torch.randn(2, 10, 9, 11)
+    x[0, :, :3, :4] = -1.0
+    c = torch.tensor([[1.0], [0.0]])
+    out = ops.g_prologue(x.to(dev), c.to(dev), 12).cpu()
+    assert torch.equal(out[..., :10], nhwc(x)) and bool((out[..., 11] == 0).all())
+    assert bool((out[0, ..., 10] == 1).all()) and bool((out[1, ..., 10] == 0).all())
+    back = ops.nhwc_to_nchw(out.to(dev), 10).cpu()
+    assert torch.equal(back, x)
+    delta = torch.randn(2, 9, 11, 12)
+    xf = ops.g_epilogue_fwd(delta.to(dev), x.to(dev)).cpu()
+    ref = torch.tanh(delta[..., :10].permute(0, 3, 1, 2) + x)
+    inv = (x == -1).float()
+    ref = ref * (1 - inv) - inv
+    assert relerr(xf, ref) <= 1e-6 and bool((xf[x == -1] == -1).all())
+    gout = torch.randn_like(x)
+    gx = torch.empty_like(x).to(dev)
+    gd = ops.g_epilogue_bwd(gout.to(dev), x.to(dev), xf.to(dev), 12, gx).cpu()
+    gref = gout * (1 - ref ** 2) * (1 - inv)
+    assert relerr(gd[..., :10], nhwc(gref)) <= 1e-5 and float(gd[..., 10:].abs().sum()) == 0
+    assert relerr(gx.cpu(), gref) <= 1e-5
+    a, b = torch.randn(4, 10, 8, 8), torch.randn(4, 10, 8, 8)
+    al = torch.rand(4)
+    lr = ops.lerp_rows(a.to(dev), b.to(dev), al.to(dev)).cpu()
+    assert relerr(lr, al.view(4, 1, 1, 1) * a + (1 - al.view(4, 1, 1, 1)) * b) <= 1e-6
+
+
+def test_diffmap_threshold_bit_exact(dev):
+    import json, os
+    import numpy as np
+    from fcd_amd import ops
+    torch.manual_seed(7)
+    x = torch.rand(3, 10, 16, 16) * 2 - 1
+    xf = (x + 0.08 * torch.randn_like(x)).clamp(-1, 1)
+    for thr in (0.02, 0.027, 0.02794):
+        diff, mask = ops.diffmap_threshold(xf.to(dev), x.to(dev), thr)
+        ref = torch.mean(torch.abs(xf - x) / 2, dim=1)
+        assert relerr(diff, ref) <= 1e-6
+        assert torch.equal(mask.cpu(), (diff.cpu() > thr).to(torch.uint8))     # same fp32 diff -> same mask
+    # fixture values at / around fp32(thr): feed them as a 1-band difference (x_fake = x + 2 v)
+    cases = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "threshold_cases.json")))
+    for thr_s, c in cases.items():
+        vals = torch.from_numpy(np.array(c["vals_bits"], dtype=np.uint32).view(np.float32).copy())
+        x0 = torch.zeros(1, 1, 1, vals.numel())
+        xf0 = (2 * vals).view(1, 1, 1, -1)                 # |xf - x| / 2 == vals exactly
+        diff, mask = ops.diffmap_threshold(xf0.to(dev), x0.to(dev), float(thr_s))
+        assert torch.equal(diff.cpu().flatten(), vals)
+        assert mask.cpu().flatten().tolist() == c["torch_gt"]
