@@ -1,0 +1,56 @@
+"""Scene-level mask generation: tile a Landsat-8 scene, run G towards "clear", stitch.
+
+Mirrors ``evaluate.predict_scene`` (``evaluate.py:84-123``) with ``PatchDataset``'s tiling
+(``data_loader.py:74-103``, crop_size 0): reflect-pad to a multiple of the patch, row-major
+patches, skip batches that are entirely nodata (all == -1), ``G(x, 0)``, ``|x_fake - x| / 2``,
+band mean, ``+=`` into a float64 raster, then ``binarize`` (numpy ``>`` in float64).
+G, the difference map and the band mean run on the GPU (HIP); tiling and stitching are host numpy
+like the reference (SURVEY 8(f) rank 1 moves them to the device later).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .synth import normalize_u16
+
+
+def scene_patches(h: int, w: int, patch: int, crop: int = 0):
+    cps = patch - 2 * crop
+    pad_h = (crop, (cps - h % cps) + crop)
+    pad_w = (crop, (cps - w % cps) + crop)
+    origins = [(r, c) for r in range(0, h, cps) for c in range(0, w, cps)]
+    return origins, pad_h, pad_w, cps
+
+
+@torch.no_grad()
+def predict_scene(full_image: np.ndarray, solver, patch_size: int = None, batch_size: int = 64) -> np.ndarray:
+    """(H, W, bands) uint16 -> (H, W) float64 difference raster.  Uses ``solver.G`` in its current
+    train/eval mode, exactly like the reference."""
+    if full_image.dtype != np.uint16:
+        raise TypeError("predict_scene expects a uint16 scene (data_loader.py:76)")
+    patch = patch_size or solver.image_size
+    h, w, _ = full_image.shape
+    origins, pad_h, pad_w, cps = scene_patches(h, w, patch, 0)
+    padded = np.pad(full_image, (pad_h, pad_w, (0, 0)), "reflect")
+    difference = np.zeros((h, w))
+    dev = solver.device
+    for s in range(0, len(origins), batch_size):
+        chunk = origins[s:s + batch_size]
+        tiles = np.stack([padded[r:r + patch, c:c + patch] for r, c in chunk])
+        x = torch.from_numpy(normalize_u16(tiles)).permute(0, 3, 1, 2).contiguous()
+        if bool((x == -1).all()):      # don't waste time on invalid patches (evaluate.py:104)
+            continue
+        delta = solver.compute_difference_map(x.to(dev)).cpu().numpy()
+        for i, (r, c) in enumerate(chunk):
+            hh, ww = min(h - r, cps), min(w - c, cps)
+            difference[r:r + hh, c:c + ww] += delta[i, :hh, :ww]
+    return difference
+
+
+def generate_scene_mask(full_image: np.ndarray, solver, threshold: float = 0.02, batch_size: int = 64):
+    """difference raster -> nodata zeroed -> ``solver.binarize`` (``evaluate.py:49-51``)."""
+    diff = predict_scene(full_image, solver, batch_size=batch_size)
+    valid = np.any(full_image != 0, axis=2)
+    diff[~valid] = 0
+    return diff, solver.binarize(diff, threshold)
