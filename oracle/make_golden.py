@@ -114,7 +114,7 @@ def sample_idx(numel, k=64, seed=7):
     return np.sort(rng.choice(numel, size=min(k, numel), replace=False))
 
 
-def run_config(cfg, store_tensors):
+def run_config(cfg, store_tensors, nsamp=64):
     gs = O.synth_generator_state(cfg["g_conv_dim"], cfg["c_dim"], cfg["g_repeat"], cfg["bands"])
     ds = O.synth_discriminator_state(cfg["size"], cfg["d_conv_dim"], cfg["c_dim"], cfg["d_repeat"], cfg["bands"])
     batch, alpha = O.synth_batch(cfg["batch"], cfg["size"], cfg["bands"])
@@ -242,6 +242,7 @@ def run_config(cfg, store_tensors):
             "g_grad_samples": {k: {"idx": sample_idx(v.numel()).tolist(),
                                    "val": v.flatten()[sample_idx(v.numel())].double().tolist()}
                                for k, v in g_grads.items()},
+            "nsamp_big": nsamp,
             "d_losses64": {k: float(v) for k, v in dl64.items()},
             "g_losses64": {k: float(v) for k, v in gl64.items()},
             "d_grad_samples64": {k: v.flatten()[sample_idx(v.numel())].tolist() for k, v in dg64.items()},
@@ -258,6 +259,16 @@ def run_config(cfg, store_tensors):
             "diff_margin_count": int(((ref_diff - thr).abs() < 1e-6).sum()),
             "oracle_vs_reference_worst_relerr": worst}
     out["scalars"] = scal
+    if nsamp > 64:
+        # larger per-tensor samples (fp32 reference and fp64 oracle) for stable rel-err estimates
+        big = {}
+        for tag, g32, g64 in (("d", d_grads, dg64), ("g", g_grads, gg64)):
+            for k in g32:
+                idx = sample_idx(g32[k].numel(), nsamp)
+                big[f"{tag}.idx.{k}"] = idx.astype(np.int64)
+                big[f"{tag}.ref32.{k}"] = g32[k].flatten()[idx].numpy()
+                big[f"{tag}.ora64.{k}"] = gg = g64[k].flatten()[idx].numpy()
+        out["big_samples"] = big
     return out
 
 
@@ -341,8 +352,9 @@ def main():
 
     if args.full:
         torch.set_num_threads(os.cpu_count())
-        r = run_config(FULL, False)
+        r = run_config(FULL, False, nsamp=4096)
         json.dump(r["scalars"], open(os.path.join(GOLD, "full_scalars.json"), "w"), indent=1)
+        np.savez_compressed(os.path.join(GOLD, "full_grad_samples.npz"), **r["big_samples"])
         print("full: worst oracle-vs-reference rel-err", r["scalars"]["oracle_vs_reference_worst_relerr"])
 
 
