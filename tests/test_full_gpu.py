@@ -112,7 +112,8 @@ def test_full_properties(full):
         o16 = s.G(b[0], b[2])
         o8 = s.G(b[0][:8].contiguous(), b[2][:8].contiguous())
         again = s.G(b[0], b[2])
-    assert torch.equal(o16[:8], o8)            # InstanceNorm couples nothing across samples
+    # InstanceNorm couples nothing across samples; only the reduction grouping depends on B
+    assert float((o16[:8] - o8).abs().max()) <= 1e-5
     assert torch.equal(o16, again)             # fixed-order reductions: bitwise reproducible
     inv = b[0] == -1
     assert bool(inv.any()) and bool((o16[inv] == -1).all())
