@@ -653,33 +653,40 @@ __global__ __launch_bounds__(256) void conv_gather_dma_kernel(const GatherArgs p
     issue_prepare(nstage, it + S - 1 < nk);
     const float4* As = smem + stage * STAGE;
     const float4* Bs = As + BM * 8;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float4 af[TM], bf[TN];
+    // fragments of step j+1 are read while the MFMAs of step j run (one wave per SIMD has
+    // nobody else to hide the LDS latency behind)
+    float4 af[2][TM], bf[2][TN];
+    auto read_frags = [&](int j, float4* a, float4* b) {
       const int c = 2 * j + lh;
 #pragma unroll
       for (int mi = 0; mi < TM; ++mi) {
         const int r = wm * WTM + mi * 32 + lr;
-        af[mi] = As[r * 8 + (c ^ ((r >> 1) & 7))];
+        a[mi] = As[r * 8 + (c ^ ((r >> 1) & 7))];
       }
 #pragma unroll
       for (int ni = 0; ni < TN; ++ni) {
         const int r = wn * WTN + ni * 32 + lr;
-        bf[ni] = Bs[r * 8 + (c ^ ((r >> 1) & 7))];
+        b[ni] = Bs[r * 8 + (c ^ ((r >> 1) & 7))];
       }
+    };
+    read_frags(0, af[0], bf[0]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (j < 3) read_frags(j + 1, af[(j + 1) & 1], bf[(j + 1) & 1]);
 #pragma unroll
       for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni) {
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].x, bf[ni].x, acc[mi][ni], 0, 0, 0);
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].y, bf[ni].y, acc[mi][ni], 0, 0, 0);
+          const float4 a = af[j & 1][mi], b = bf[j & 1][ni];
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[mi][ni], 0, 0, 0);
           // the next tile's DMA issue rides in the shadow of the 64-cycle MFMAs
           const int g = (j * TM + mi) * TN + ni;
 #pragma unroll
           for (int q = 0; q < ND; ++q)
             if (q * G / ND == g && !(p.dbg & 1)) issue_one(q);
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].z, bf[ni].z, acc[mi][ni], 0, 0, 0);
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].w, bf[ni].w, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[mi][ni], 0, 0, 0);
         }
     }
     issue_advance();
@@ -688,22 +695,52 @@ __global__ __launch_bounds__(256) void conv_gather_dma_kernel(const GatherArgs p
   }
   __syncthreads();   // rowoff visible even when nk == 0
 
+  // epilogue: D[row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)][col = lane&31]; the optional operand
+  // loads of a 32x32 tile are issued together so that their latencies overlap
   float* __restrict__ dst = p.splitk > 1 ? p.slab + (long)blockIdx.y * p.M * p.CoutP : p.out;
+  const bool fin = p.splitk == 1;
 #pragma unroll
   for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni) {
       const int co = tn * BN + wn * WTN + ni * 32 + lr;
       if (co >= p.CoutP) continue;
+      const bool cok = co < p.Cout;
+      long off[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wm * WTM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const long off = rowoff[row];
-        if (off < 0) continue;
-        float v = acc[mi][ni][r];
-        if (p.splitk == 1) v = co < p.Cout ? epilogue_value(v, co, off + co, p) : 0.f;
-        dst[off + co] = v;
+      for (int r = 0; r < 16; ++r) off[r] = rowoff[wm * WTM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
+      float v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = acc[mi][ni][r];
+      if (fin) {
+        const float bs = (p.bias && cok) ? p.bias[co] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          v[r] += bs;
+          v[r] = v[r] > 0.f ? v[r] : v[r] * p.act_slope;
+        }
+        if (p.mask) {
+          float mk[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) mk[r] = (off[r] >= 0 && cok) ? p.mask[off[r] + co] : 1.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] *= mk[r] > 0.f ? 1.f : p.mask_slope;
+        }
+        if (p.res) {
+          float rs[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) rs[r] = (off[r] >= 0 && cok) ? p.res[off[r] + co] : 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] += rs[r];
+        }
+        if (!cok) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = 0.f;
+        }
       }
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (off[r] >= 0) dst[off[r] + co] = v[r];
     }
 }
 
@@ -812,19 +849,25 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradArgs p, 
     issue_prepare(nstage, it + S - 1 < nk);
     const float* As = smem + stage * STAGE;
     const float* Bs = As + 32 * BM;
-#pragma unroll
-    for (int kk = 0; kk < 16; ++kk) {
-      float af[TM], bf[TN];
+    // operands of k-step kk+2 are read while the MFMAs of step kk run
+    float af[3][TM], bf[3][TN];
+    auto read_frags = [&](int kk, float* a, float* b) {
       const int kq = 2 * kk + lh;
 #pragma unroll
-      for (int mi = 0; mi < TM; ++mi) af[mi] = As[kq * BM + wm * WTM + mi * 32 + lr];
+      for (int mi = 0; mi < TM; ++mi) a[mi] = As[kq * BM + wm * WTM + mi * 32 + lr];
 #pragma unroll
-      for (int ni = 0; ni < TN; ++ni) bf[ni] = Bs[kq * BN + wn * WTN + ni * 32 + lr];
+      for (int ni = 0; ni < TN; ++ni) b[ni] = Bs[kq * BN + wn * WTN + ni * 32 + lr];
+    };
+    read_frags(0, af[0], bf[0]);
+    read_frags(1, af[1], bf[1]);
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      if (kk + 2 < 16) read_frags(kk + 2, af[(kk + 2) % 3], bf[(kk + 2) % 3]);
 #pragma unroll
       for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk % 3][mi], bf[kk % 3][ni], acc[mi][ni], 0, 0, 0);
       // the next tile's DMA issue rides in the shadow of the MFMAs
 #pragma unroll
       for (int q = 0; q < ND; ++q)
