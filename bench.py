@@ -86,6 +86,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--precision", default=os.environ.get("FCD_PRECISION", "fp32"), choices=["fp32", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default=os.environ.get("FCD_DIST_BACKEND", "nccl"),
+                    help="torch.distributed backend: nccl (= RCCL over xGMI); gloo only to rehearse the "
+                         "multi-rank code path on a box with fewer GPUs than ranks")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -93,17 +96,24 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the FCD hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    if args.backend == "nccl" and local_rank >= ndev:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {ndev} GPU(s) visible")
+    dev_index = local_rank % ndev
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     from fcd_amd import FCDSolver, _lib
     from fcd_amd.parallel import GradSync
     from fcd_amd.synth import synth_batch
-    _lib.check(_lib.load().fcd_init(local_rank), "fcd_init")
+    _lib.check(_lib.load().fcd_init(dev_index), "fcd_init")
 
     torch.manual_seed(8888)
     solver = FCDSolver(None, batch_size=BASE["batch"], precision=args.precision).to(dev)
@@ -140,7 +150,7 @@ def main():
         res = {"metric": "FCD train images/sec (G+D step, 128x128 multispectral)", "value": round(value, 2),
                "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "f32" if args.precision == "fp32" else "bf16",
+               "dtype": "fp32" if args.precision == "fp32" else "bf16",
                "data": "synthetic (numpy PCG64 uint16 patches -> [-1,1], nodata rectangle; random-init weights)",
                "config": {"workload": "FCD G+D train step incl. gradient penalty, batch 16/GPU, 128x128x10, "
                                       "6 res blocks, D x6 (BASELINE.json configs[1])",
