@@ -4,9 +4,9 @@
 //                       (forward conv, transposed conv by 4 phases, data gradients)
 //   conv_wgrad_kernel   dw[o][tap,i]   = sum_pixel gs[pixel][o] * xb[gather(pixel,tap)][i]
 //
-// Both stage their operand tiles through LDS with 16-byte loads and feed
-// v_mfma_f32_32x32x2_f32 (exact fp32 fma chain) or v_mfma_f32_32x32x16_bf16
-// (operands rounded to bf16 while staging, fp32 accumulate).  A workgroup is 4
+// Both move their operand tiles global -> LDS by LDS-DMA and feed v_mfma_f32_32x32x2_f32 (exact
+// fp32 fma chain) or v_mfma_f32_32x32x16_bf16 (operands rounded to bf16 when the fragments are
+// read from the fp32 LDS image, fp32 accumulate).  A workgroup is 4
 // wavefronts of 64 lanes; each wave owns a (BM/WM) x (BN/WN) block of 32x32
 // accumulator tiles.  Split-K partial sums go to caller-provided slabs and are
 // combined in a fixed order by a second kernel, so results are bitwise
@@ -15,6 +15,7 @@
 #include <stdlib.h>
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
@@ -32,7 +33,7 @@ struct GatherArgs {
   int M, ktiles, ktiles_per_split, tiles_m, tiles_n;
   long w_phase_stride;
   float act_slope, mask_slope;
-  int dbg;
+  int tap_inner;   // K-tiles run taps-inside-channel-slices (needs Cin % 32 == 0)
 };
 
 __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
@@ -50,207 +51,6 @@ __device__ __forceinline__ float epilogue_value(float v, int co, long o, const G
   if (p.mask) v *= (p.mask[o] > 0.f ? 1.f : p.mask_slope);
   if (p.res) v += p.res[o];
   return v;
-}
-
-// One 16-byte LDS chunk holds KPC consecutive k: 4 fp32 or 8 bf16.  A K tile is 8 chunks per
-// row; chunk c of row r lives at slot c ^ ((r >> 1) & 7) so that the 16 rows a ds_read_b128
-// lane group touches fall on 16 different 16-byte bank slots.
-template <int BM, int BN, int WM, int WN, bool BF16>
-__global__ __launch_bounds__(256) void conv_gather_kernel(const GatherArgs p) {
-  constexpr int KPC = BF16 ? 8 : 4;       // k per chunk
-  constexpr int BK = 8 * KPC;             // k per tile
-  constexpr int NG = BF16 ? 2 : 1;        // float4 global loads per chunk
-  constexpr int WTM = BM / WM, WTN = BN / WN;
-  constexpr int TM = WTM / 32, TN = WTN / 32;
-  constexpr int AL = BM / 32, BL = BN / 32;  // chunks per thread per tile
-  static_assert(WM * WN == 4, "4 waves");
-
-  __shared__ float4 As[BM * 8];
-  __shared__ float4 Bs[BN * 8];
-  __shared__ long rowoff[BM];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN;
-  const int tn = blockIdx.x % p.tiles_n, tm = blockIdx.x / p.tiles_n;
-  const int phase = blockIdx.y / p.splitk, ks = blockIdx.y % p.splitk;
-  const int pad_h = p.pad_h[phase], pad_w = p.pad_w[phase];
-  const float* __restrict__ wph = p.w + (long)phase * p.w_phase_stride;
-
-  const int ghw = p.GH * p.GW;
-  // output offsets of this tile's rows (or -1)
-  for (int r = tid; r < BM; r += 256) {
-    const int m = tm * BM + r;
-    long off = -1;
-    if (m < p.M) {
-      const int n = m / ghw, rem = m - n * ghw;
-      const int a = rem / p.GW, b = rem - a * p.GW;
-      if (p.splitk > 1) {
-        off = (long)m * p.CoutP;
-      } else {
-        off = (((long)n * p.OH + a * p.ostride + p.ooff_h[phase]) * p.OW + b * p.ostride +
-               p.ooff_w[phase]) * p.CoutP;
-      }
-    }
-    rowoff[r] = off;
-  }
-
-  // rows this thread gathers: r = (tid >> 3) + 32*i, chunk kc = tid & 7
-  const int kc = tid & 7, r0 = tid >> 3;
-  int a_ih0[AL], a_iw0[AL];
-  long a_base[AL];
-#pragma unroll
-  for (int i = 0; i < AL; ++i) {
-    const int m = tm * BM + r0 + 32 * i;
-    if (m < p.M) {
-      const int n = m / ghw, rem = m - n * ghw;
-      const int a = rem / p.GW, b = rem - a * p.GW;
-      a_ih0[i] = a * p.istride - pad_h;
-      a_iw0[i] = b * p.istride - pad_w;
-      a_base[i] = (long)n * p.IH * p.IW;
-    } else {
-      a_ih0[i] = -(1 << 28);
-      a_iw0[i] = 0;
-      a_base[i] = 0;
-    }
-  }
-
-  float4 areg[AL][NG], breg[BL][NG];
-
-  auto load_tile = [&](int kt) {
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      const int k = kt * BK + kc * KPC + g * 4;
-      const bool kok = k < p.K;
-      const int tap = k / p.Cin, ci = k - tap * p.Cin;
-      const int th = tap / p.KW, tw = tap - th * p.KW;
-#pragma unroll
-      for (int i = 0; i < AL; ++i) {
-        const int ih = a_ih0[i] + th, iw = a_iw0[i] + tw;
-        const bool ok = kok && ih >= 0 && ih < p.IH && iw >= 0 && iw < p.IW;
-        areg[i][g] = ok ? ldg4(p.in + (a_base[i] + (long)ih * p.IW + iw) * p.Cin + ci)
-                        : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-#pragma unroll
-      for (int i = 0; i < BL; ++i) {
-        const int co = tn * BN + r0 + 32 * i;
-        const bool ok = kok && co < p.Cout;
-        breg[i][g] = ok ? ldg4(wph + (long)co * p.K + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    }
-  };
-
-  auto store_tile = [&]() {
-#pragma unroll
-    for (int i = 0; i < AL; ++i) {
-      const int r = r0 + 32 * i;
-      float4 v;
-      if constexpr (BF16) {
-        v.x = __uint_as_float(pack_bf16x2(areg[i][0].x, areg[i][0].y));
-        v.y = __uint_as_float(pack_bf16x2(areg[i][0].z, areg[i][0].w));
-        v.z = __uint_as_float(pack_bf16x2(areg[i][NG - 1].x, areg[i][NG - 1].y));
-        v.w = __uint_as_float(pack_bf16x2(areg[i][NG - 1].z, areg[i][NG - 1].w));
-      } else {
-        v = areg[i][0];
-      }
-      As[r * 8 + (kc ^ ((r >> 1) & 7))] = v;
-    }
-#pragma unroll
-    for (int i = 0; i < BL; ++i) {
-      const int r = r0 + 32 * i;
-      float4 v;
-      if constexpr (BF16) {
-        v.x = __uint_as_float(pack_bf16x2(breg[i][0].x, breg[i][0].y));
-        v.y = __uint_as_float(pack_bf16x2(breg[i][0].z, breg[i][0].w));
-        v.z = __uint_as_float(pack_bf16x2(breg[i][NG - 1].x, breg[i][NG - 1].y));
-        v.w = __uint_as_float(pack_bf16x2(breg[i][NG - 1].z, breg[i][NG - 1].w));
-      } else {
-        v = breg[i][0];
-      }
-      Bs[r * 8 + (kc ^ ((r >> 1) & 7))] = v;
-    }
-  };
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int kt0 = ks * p.ktiles_per_split;
-  const int kt1 = min(p.ktiles, kt0 + p.ktiles_per_split);
-  const int lr = lane & 31, lh = lane >> 5;
-
-  if (kt0 < kt1) {
-    load_tile(kt0);
-    store_tile();
-  }
-  __syncthreads();
-
-  for (int kt = kt0; kt < kt1; ++kt) {
-    const bool more = kt + 1 < kt1;
-    if (more) load_tile(kt + 1);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float4 af[TM], bf[TN];
-      const int c = 2 * j + lh;
-#pragma unroll
-      for (int mi = 0; mi < TM; ++mi) {
-        const int r = wm * WTM + mi * 32 + lr;
-        af[mi] = As[r * 8 + (c ^ ((r >> 1) & 7))];
-      }
-#pragma unroll
-      for (int ni = 0; ni < TN; ++ni) {
-        const int r = wn * WTN + ni * 32 + lr;
-        bf[ni] = Bs[r * 8 + (c ^ ((r >> 1) & 7))];
-      }
-      if constexpr (BF16) {
-#pragma unroll
-        for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < TN; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                __builtin_bit_cast(bf16x8_t, af[mi]), __builtin_bit_cast(bf16x8_t, bf[ni]),
-                acc[mi][ni], 0, 0, 0);
-      } else {
-        // lane half h supplies k = 8j + 4h + e for element e: pairs (e, 4 + e) per MFMA
-#pragma unroll
-        for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < TN; ++ni) {
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].x, bf[ni].x, acc[mi][ni], 0, 0, 0);
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].y, bf[ni].y, acc[mi][ni], 0, 0, 0);
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].z, bf[ni].z, acc[mi][ni], 0, 0, 0);
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].w, bf[ni].w, acc[mi][ni], 0, 0, 0);
-          }
-      }
-    }
-    __syncthreads();
-    if (more) {
-      store_tile();
-      __syncthreads();
-    }
-  }
-
-  // epilogue: D[row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)][col = lane&31]
-  float* __restrict__ dst = p.splitk > 1 ? p.slab + (long)blockIdx.y * p.M * p.CoutP : p.out;
-#pragma unroll
-  for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < TN; ++ni) {
-      const int co = tn * BN + wn * WTN + ni * 32 + lr;
-      if (co >= p.CoutP) continue;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wm * WTM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const long off = rowoff[row];
-        if (off < 0) continue;
-        float v = acc[mi][ni][r];
-        if (p.splitk == 1) v = co < p.Cout ? epilogue_value(v, co, off + co, p) : 0.f;
-        dst[off + co] = v;
-      }
-    }
 }
 
 // Sum the split-K slabs in a fixed order, apply the epilogue, scatter to the output pixels.
@@ -281,154 +81,6 @@ struct WgradArgs {
   int N, GH, GW, O, OP, BH, BW, I, IP, KH, KW, stride, pad;
   int P, ND, splitk, ktiles, ktiles_per_split, tiles_m, tiles_n, accumulate;
 };
-
-template <int BM, int BN, int WM, int WN, bool BF16>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
-  // K runs over pixels; both operand tiles are [pixel][column] in memory and in LDS.
-  constexpr int BK = 32;
-  constexpr int WTM = BM / WM, WTN = BN / WN;
-  constexpr int TM = WTM / 32, TN = WTN / 32;
-  constexpr int ACOLS = BM / 4, BCOLS = BN / 4;          // float4 columns
-  constexpr int AROWS = 256 / ACOLS, BROWS = 256 / BCOLS;  // pixel rows per pass
-  constexpr int AL = BK / AROWS, BL = BK / BROWS;
-  constexpr int LDA = BM + 4, LDB = BN + 4;   // +4 floats: lane halves land on different banks
-
-  __shared__ float As[BK * LDA];
-  __shared__ float Bs[BK * LDB];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN;
-  const int tn = blockIdx.x % p.tiles_n, tm = blockIdx.x / p.tiles_n;
-  const int ks = blockIdx.y;
-  const int ghw = p.GH * p.GW;
-
-  const int acol = tid % ACOLS, arow0 = tid / ACOLS;
-  const int bcol = tid % BCOLS, brow0 = tid / BCOLS;
-  const int o0 = tm * BM + acol * 4;
-  const bool a_ok = o0 < p.OP;
-  const int nd = tn * BN + bcol * 4;
-  const bool b_ok = nd < p.ND;
-  const int tap = nd / p.IP, ci = nd - tap * p.IP;
-  const int th = tap / p.KW, tw = tap - th * p.KW;
-
-  float4 areg[AL], breg[BL];
-
-  auto load_tile = [&](int kt) {
-#pragma unroll
-    for (int i = 0; i < AL; ++i) {
-      const int px = kt * BK + arow0 + AROWS * i;
-      areg[i] = (a_ok && px < p.P) ? ldg4(p.gs + (long)px * p.OP + o0) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-#pragma unroll
-    for (int i = 0; i < BL; ++i) {
-      const int px = kt * BK + brow0 + BROWS * i;
-      bool ok = b_ok && px < p.P;
-      long off = 0;
-      if (ok) {
-        const int n = px / ghw, rem = px - n * ghw;
-        const int a = rem / p.GW, b = rem - a * p.GW;
-        const int ih = a * p.stride - p.pad + th, iw = b * p.stride - p.pad + tw;
-        ok = ih >= 0 && ih < p.BH && iw >= 0 && iw < p.BW;
-        off = (((long)n * p.BH + ih) * p.BW + iw) * p.IP + ci;
-      }
-      breg[i] = ok ? ldg4(p.xb + off) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  };
-  auto store_tile = [&]() {
-#pragma unroll
-    for (int i = 0; i < AL; ++i)
-      *reinterpret_cast<float4*>(&As[(arow0 + AROWS * i) * LDA + acol * 4]) = areg[i];
-#pragma unroll
-    for (int i = 0; i < BL; ++i)
-      *reinterpret_cast<float4*>(&Bs[(brow0 + BROWS * i) * LDB + bcol * 4]) = breg[i];
-  };
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int kt0 = ks * p.ktiles_per_split;
-  const int kt1 = min(p.ktiles, kt0 + p.ktiles_per_split);
-  const int lr = lane & 31, lh = lane >> 5;
-
-  if (kt0 < kt1) {
-    load_tile(kt0);
-    store_tile();
-  }
-  __syncthreads();
-  for (int kt = kt0; kt < kt1; ++kt) {
-    const bool more = kt + 1 < kt1;
-    if (more) load_tile(kt + 1);
-    if constexpr (BF16) {
-      // bf16: lane half h needs k = 8h..8h+7 of a 16-pixel step; gather them from 8 LDS rows
-#pragma unroll
-      for (int j = 0; j < BK / 16; ++j) {
-        unsigned au[TM][4], bu[TN][4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int k = j * 16 + lh * 8 + e * 2;
-#pragma unroll
-          for (int mi = 0; mi < TM; ++mi) {
-            const int c = wm * WTM + mi * 32 + lr;
-            au[mi][e] = pack_bf16x2(As[k * LDA + c], As[(k + 1) * LDA + c]);
-          }
-#pragma unroll
-          for (int ni = 0; ni < TN; ++ni) {
-            const int c = wn * WTN + ni * 32 + lr;
-            bu[ni][e] = pack_bf16x2(Bs[k * LDB + c], Bs[(k + 1) * LDB + c]);
-          }
-        }
-#pragma unroll
-        for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < TN; ++ni) {
-            uint4 ua = make_uint4(au[mi][0], au[mi][1], au[mi][2], au[mi][3]);
-            uint4 ub = make_uint4(bu[ni][0], bu[ni][1], bu[ni][2], bu[ni][3]);
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                __builtin_bit_cast(bf16x8_t, ua), __builtin_bit_cast(bf16x8_t, ub), acc[mi][ni], 0, 0, 0);
-          }
-      }
-    } else {
-#pragma unroll
-      for (int kk = 0; kk < BK / 2; ++kk) {
-        float af[TM], bf[TN];
-        const int k = 2 * kk + lh;
-#pragma unroll
-        for (int mi = 0; mi < TM; ++mi) af[mi] = As[k * LDA + wm * WTM + mi * 32 + lr];
-#pragma unroll
-        for (int ni = 0; ni < TN; ++ni) bf[ni] = Bs[k * LDB + wn * WTN + ni * 32 + lr];
-#pragma unroll
-        for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < TN; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
-      }
-    }
-    __syncthreads();
-    if (more) {
-      store_tile();
-      __syncthreads();
-    }
-  }
-
-  float* __restrict__ dst = p.slab + (long)ks * p.O * p.ND;
-#pragma unroll
-  for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < TN; ++ni) {
-      const int col = tn * BN + wn * WTN + ni * 32 + lr;
-      if (col >= p.ND) continue;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int o = tm * BM + wm * WTM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (o < p.O) dst[(long)o * p.ND + col] = acc[mi][ni][r];
-      }
-    }
-}
 
 // slabs [splitk][O][KH*KW*IP] -> parameter layout [O][I][KH][KW]
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs p) {
@@ -520,14 +172,16 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
-template <int BM, int BN, int WM, int WN, int S>
-__global__ __launch_bounds__(256) void conv_gather_dma_kernel(const GatherArgs p, const unsigned in_bytes,
-                                                              const unsigned w_bytes) {
+template <int BM, int BN, int WM, int WN, int S, bool BF16>
+__global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const GatherArgs p, const unsigned in_bytes,
+                                                                       const unsigned w_bytes) {
+  constexpr int NW = WM * WN, NT = 64 * NW;     // 4 waves (one per SIMD) or 8 (two per SIMD)
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
-  constexpr int AL = BM / 32, BL = BN / 32;     // DMA instructions per wave per K-tile
+  constexpr int RPI = 8 * NW;                   // tile rows one DMA instruction of every wave covers
+  constexpr int AL = BM / RPI, BL = BN / RPI;   // DMA instructions per wave per K-tile
   constexpr int STAGE = (BM + BN) * 8;          // float4 chunks per stage
-  static_assert(WM * WN == 4 && S >= 2, "shape");
+  static_assert((NW == 4 || NW == 8) && S >= 2 && BM % RPI == 0 && BN % RPI == 0 && TM >= 1 && TN >= 1, "shape");
 
   __shared__ float4 smem[S * STAGE + BM / 2];   // ring + rowoff (BM longs)
   long* rowoff = reinterpret_cast<long*>(smem + S * STAGE);
@@ -541,7 +195,7 @@ __global__ __launch_bounds__(256) void conv_gather_dma_kernel(const GatherArgs p
   const int pad_h = p.pad_h[phase], pad_w = p.pad_w[phase];
   const int ghw = p.GH * p.GW;
 
-  for (int r = tid; r < BM; r += 256) {
+  for (int r = tid; r < BM; r += NT) {
     const int m = tm * BM + r;
     long off = -1;
     if (m < p.M) {
@@ -558,7 +212,7 @@ __global__ __launch_bounds__(256) void conv_gather_dma_kernel(const GatherArgs p
   const i32x4 rw = make_rsrc(p.w + (long)phase * p.w_phase_stride, w_bytes);
   const unsigned lds0 = lds_addr_of(smem);
 
-  // this lane fills slot (lane&7) of row rl = 8*wave + (lane>>3) (+32 per instruction); the slot
+  // this lane fills slot (lane&7) of row rl = 8*wave + (lane>>3) (+RPI per instruction); the slot
   // holds chunk kc = slot ^ ((row>>1)&7): the swizzle lives in the SOURCE address.
   const int rl = 8 * wave + (lane >> 3);
   const int kc = (lane & 7) ^ ((rl >> 1) & 7);
@@ -566,7 +220,7 @@ __global__ __launch_bounds__(256) void conv_gather_dma_kernel(const GatherArgs p
   unsigned a_mh[AL], a_mw[AL];
 #pragma unroll
   for (int i = 0; i < AL; ++i) {
-    const int m = tm * BM + rl + 32 * i;
+    const int m = tm * BM + rl + RPI * i;
     a_base[i] = 0;
     a_mh[i] = a_mw[i] = 0u;
     if (m < p.M) {
@@ -581,7 +235,7 @@ __global__ __launch_bounds__(256) void conv_gather_dma_kernel(const GatherArgs p
   unsigned b_base[BL];
 #pragma unroll
   for (int i = 0; i < BL; ++i) {
-    const int co = tn * BN + rl + 32 * i;
+    const int co = tn * BN + rl + RPI * i;
     b_base[i] = co < p.Cout ? (unsigned)(co * p.K * 4) : OOB;
   }
 
@@ -589,9 +243,21 @@ __global__ __launch_bounds__(256) void conv_gather_dma_kernel(const GatherArgs p
   const int kt1 = min(p.ktiles, kt0 + p.ktiles_per_split);
   const int nk = kt1 - kt0;
 
-  // running decomposition of this lane's k = kt*32 + kc*4 into (th, tw, ci)
-  int k = kt0 * 32 + kc * 4;
-  int tap = k / p.Cin, ci = k - tap * p.Cin;
+  // running decomposition of this lane's k into (th, tw, ci).  Packed order is k = tap*Cin + ci;
+  // K-tile number q covers k = 32q.. in that order, or - tap_inner - tap q % T of channel slice
+  // q / T: all taps of a 32-channel slice back to back, so that the up-to-T re-reads of an input
+  // line are a few K-tiles apart and hit in L2 instead of a whole channel sweep apart.
+  const int T = p.KH * p.KW;
+  int k, tap, ci;
+  if (p.tap_inner) {
+    tap = kt0 % T;
+    ci = (kt0 / T) * 32 + kc * 4;
+    k = tap * p.Cin + ci;
+  } else {
+    k = kt0 * 32 + kc * 4;
+    tap = k / p.Cin;
+    ci = k - tap * p.Cin;
+  }
   int th = tap / p.KW, tw = tap - th * p.KW;
 
   // Every lane issues exactly AL + BL DMA instructions per K-tile with full EXEC (the counted
@@ -611,18 +277,24 @@ __global__ __launch_bounds__(256) void conv_gather_dma_kernel(const GatherArgs p
     if (q < AL) {
       const unsigned okm = (0u - ((a_mh[q] >> thc) & (a_mw[q] >> tw) & 1u)) & live;   // all ones when valid
       const unsigned voff = (((unsigned)a_base[q] + tapoff) & okm) | (OOB & ~okm);
-      dma16(rin, voff, la + q * (32 * 8 * 16));
+      dma16(rin, voff, la + q * (RPI * 8 * 16));
     } else {
       const unsigned voff = (b_base[q - AL] + (unsigned)(k * 4)) | (OOB & ~live);   // invalid rows stay >= OOB
-      dma16(rw, voff, lb + (q - AL) * (32 * 8 * 16));
+      dma16(rw, voff, lb + (q - AL) * (RPI * 8 * 16));
     }
   };
   auto issue_advance = [&]() {
-    k += 32;
-    ci += 32;
-    while (ci >= p.Cin) {
-      ci -= p.Cin;
+    if (p.tap_inner) {
+      k += p.Cin;
       if (++tw == p.KW) { tw = 0; ++th; }
+      if (th == p.KH) { th = 0; ci += 32; k += 32 - T * p.Cin; }
+    } else {
+      k += 32;
+      ci += 32;
+      while (ci >= p.Cin) {
+        ci -= p.Cin;
+        if (++tw == p.KW) { tw = 0; ++th; }
+      }
     }
   };
 
@@ -649,10 +321,43 @@ __global__ __launch_bounds__(256) void conv_gather_dma_kernel(const GatherArgs p
   for (int it = 0; it < nk; ++it) {
     // exactly ND*(S-2) younger DMAs are in flight behind tile `it`: keep them flying
     wait_vmcnt<ND * (S - 2)>();
-    if (!(p.dbg & 2)) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();
     issue_prepare(nstage, it + S - 1 < nk);
     const float4* As = smem + stage * STAGE;
     const float4* Bs = As + BM * 8;
+    if constexpr (BF16) {
+      // bf16 MFMA on the same fp32 LDS image: lane half h of k16-step s owns k = 16s + 8h .. +7
+      // (two 16-byte chunks), rounded to bf16 in registers (v_cvt_pk_bf16_f32)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        bf16x8_t af[TM], bf[TN];
+        const int c0 = 4 * s2 + 2 * lh;
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+          const int r = wm * WTM + mi * 32 + lr, sw = (r >> 1) & 7;
+          const float4 lo = As[r * 8 + (c0 ^ sw)], hi = As[r * 8 + ((c0 + 1) ^ sw)];
+          const f32x8 f = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+          af[mi] = __builtin_convertvector(f, bf16x8_t);
+        }
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+          const int r = wn * WTN + ni * 32 + lr, sw = (r >> 1) & 7;
+          const float4 lo = Bs[r * 8 + (c0 ^ sw)], hi = Bs[r * 8 + ((c0 + 1) ^ sw)];
+          const f32x8 f = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+          bf[ni] = __builtin_convertvector(f, bf16x8_t);
+        }
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < TN; ++ni) {
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+            const int g = (s2 * TM + mi) * TN + ni;
+#pragma unroll
+            for (int q = 0; q < ND; ++q)
+              if (q * (2 * TM * TN) / ND == g) issue_one(q);
+          }
+      }
+    } else {
     // fragments of step j+1 are read while the MFMAs of step j run (one wave per SIMD has
     // nobody else to hide the LDS latency behind)
     float4 af[2][TM], bf[2][TN];
@@ -673,21 +378,23 @@ __global__ __launch_bounds__(256) void conv_gather_dma_kernel(const GatherArgs p
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       if (j < 3) read_frags(j + 1, af[(j + 1) & 1], bf[(j + 1) & 1]);
+      // consecutive MFMAs go to different accumulators (a dependent one would wait for the
+      // previous result to leave the pipe); the next tile's DMA issue rides in their shadow
 #pragma unroll
-      for (int mi = 0; mi < TM; ++mi)
+      for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int ni = 0; ni < TN; ++ni) {
-          const float4 a = af[j & 1][mi], b = bf[j & 1][ni];
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[mi][ni], 0, 0, 0);
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[mi][ni], 0, 0, 0);
-          // the next tile's DMA issue rides in the shadow of the 64-cycle MFMAs
-          const int g = (j * TM + mi) * TN + ni;
+        for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
-          for (int q = 0; q < ND; ++q)
-            if (q * G / ND == g && !(p.dbg & 1)) issue_one(q);
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[mi][ni], 0, 0, 0);
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[mi][ni], 0, 0, 0);
-        }
+          for (int ni = 0; ni < TN; ++ni) {
+            const float a = e == 0 ? af[j & 1][mi].x : e == 1 ? af[j & 1][mi].y : e == 2 ? af[j & 1][mi].z : af[j & 1][mi].w;
+            const float b = e == 0 ? bf[j & 1][ni].x : e == 1 ? bf[j & 1][ni].y : e == 2 ? bf[j & 1][ni].z : bf[j & 1][ni].w;
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[mi][ni], 0, 0, 0);
+            const int g = ((j * 4 + e) * TM + mi) * TN + ni;      // 0 .. 4*G-1
+#pragma unroll
+            for (int q = 0; q < ND; ++q)
+              if (q * (4 * G) / ND + 1 == g) issue_one(q);
+          }
+    }
     }
     issue_advance();
     stage = stage + 1 == S ? 0 : stage + 1;
@@ -746,15 +453,16 @@ __global__ __launch_bounds__(256) void conv_gather_dma_kernel(const GatherArgs p
 
 // Weight gradient, fp32, LDS-DMA ring.  LDS tiles are [32 pixels][BM | BN] floats, unpadded (one
 // DMA instruction of a wave writes 1 KiB = 256/BM consecutive pixel rows).
-template <int BM, int BN, int WM, int WN, int S>
-__global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradArgs p, const unsigned gs_bytes,
-                                                             const unsigned xb_bytes) {
+template <int BM, int BN, int WM, int WN, int S, bool BF16>
+__global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_dma_kernel(const WgradArgs p, const unsigned gs_bytes,
+                                                                      const unsigned xb_bytes) {
+  constexpr int NW = WM * WN;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
-  constexpr int AL = BM / 32, BL = BN / 32;
+  constexpr int AL = BM / (8 * NW), BL = BN / (8 * NW);
   constexpr int ARPI = 256 / BM, BRPI = 256 / BN;     // pixel rows per DMA instruction
   constexpr int STAGE = 32 * (BM + BN);               // floats per stage
-  static_assert(WM * WN == 4 && S >= 2, "shape");
+  static_assert((NW == 4 || NW == 8) && S >= 2 && BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && TM >= 1 && TN >= 1, "shape");
 
   __shared__ float smem[S * STAGE];
 
@@ -779,7 +487,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradArgs p, 
   const bool a_colok = o0 < p.OP;
   int a_px[AL];
 #pragma unroll
-  for (int i = 0; i < AL; ++i) a_px[i] = kt0 * 32 + (i * 4 + wave) * ARPI + a_row;
+  for (int i = 0; i < AL; ++i) a_px[i] = kt0 * 32 + (i * NW + wave) * ARPI + a_row;
 
   // B (xb gathered at this lane's tap): column -> (tap, ci)
   const int b_row = lane / (BN / 4), b_col = (lane % (BN / 4)) * 4;
@@ -791,7 +499,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradArgs p, 
   int b_px[BL], b_n[BL], b_a[BL], b_b[BL];
 #pragma unroll
   for (int i = 0; i < BL; ++i) {
-    b_px[i] = kt0 * 32 + (i * 4 + wave) * BRPI + b_row;
+    b_px[i] = kt0 * 32 + (i * NW + wave) * BRPI + b_row;
     b_n[i] = b_px[i] / ghw;
     const int rem = b_px[i] - b_n[i] * ghw;
     b_a[i] = rem / p.GW;
@@ -809,14 +517,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradArgs p, 
     if (q < AL) {
       const unsigned okm = (0u - (unsigned)(a_colok & (a_px[q] < p.P))) & live;
       const unsigned voff = ((unsigned)((a_px[q] * p.OP + o0) * 4) & okm) | (OOB & ~okm);
-      dma16(rgs, voff, la + q * 4096);
+      dma16(rgs, voff, la + q * (NW * 1024));
       a_px[q] += 32;
     } else {
       const int i = q - AL;
       const int ih = b_a[i] * p.stride - p.pad + th, iw = b_b[i] * p.stride - p.pad + tw;
       const unsigned okm = (0u - (unsigned)(b_colok & (b_px[i] < p.P) & (ih >= 0) & (ih < p.BH) & (iw >= 0) & (iw < p.BW))) & live;
       const unsigned voff = ((unsigned)((((b_n[i] * p.BH + ih) * p.BW + iw) * p.IP + ci) * 4) & okm) | (OOB & ~okm);
-      dma16(rxb, voff, lb + i * 4096);
+      dma16(rxb, voff, lb + i * (NW * 1024));
       b_px[i] += 32;
       b_b[i] += 32;
       while (b_b[i] >= p.GW) {
@@ -849,6 +557,36 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradArgs p, 
     issue_prepare(nstage, it + S - 1 < nk);
     const float* As = smem + stage * STAGE;
     const float* Bs = As + 32 * BM;
+    if constexpr (BF16) {
+      // k = pixel: lane half h of k16-step s owns pixels 16s + 8h .. +7 of its column
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        bf16x8_t af[TM], bf[TN];
+        const int k0 = 16 * s2 + 8 * lh;
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+          const float* c = As + k0 * BM + wm * WTM + mi * 32 + lr;
+          const f32x8 f = {c[0], c[BM], c[2 * BM], c[3 * BM], c[4 * BM], c[5 * BM], c[6 * BM], c[7 * BM]};
+          af[mi] = __builtin_convertvector(f, bf16x8_t);
+        }
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+          const float* c = Bs + k0 * BN + wn * WTN + ni * 32 + lr;
+          const f32x8 f = {c[0], c[BN], c[2 * BN], c[3 * BN], c[4 * BN], c[5 * BN], c[6 * BN], c[7 * BN]};
+          bf[ni] = __builtin_convertvector(f, bf16x8_t);
+        }
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < TN; ++ni) {
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+            const int g = (s2 * TM + mi) * TN + ni;
+#pragma unroll
+            for (int q = 0; q < ND; ++q)
+              if (q * (2 * TM * TN) / ND == g) issue_one(q);
+          }
+      }
+    } else {
     // operands of k-step kk+2 are read while the MFMAs of step kk run
     float af[3][TM], bf[3][TN];
     auto read_frags = [&](int kk, float* a, float* b) {
@@ -872,6 +610,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradArgs p, 
 #pragma unroll
       for (int q = 0; q < ND; ++q)
         if (q * 16 / ND == kk) issue_one(q);
+    }
     }
     stage = stage + 1 == S ? 0 : stage + 1;
     nstage = nstage + 1 == S ? 0 : nstage + 1;
@@ -932,26 +671,24 @@ __global__ __launch_bounds__(256) void pack_adj_kernel(const float* __restrict__
 template <int BM, int BN, int WM, int WN>
 int launch_gather(const GatherArgs& a, int precision, hipStream_t st) {
   dim3 grid(a.tiles_m * a.tiles_n, a.nphase * a.splitk);
-  if (precision == FCD_PREC_BF16) {
-    hipLaunchKernelGGL((conv_gather_kernel<BM, BN, WM, WN, true>), grid, dim3(256), 0, st, a);
-  } else {
-    const unsigned in_bytes = (unsigned)((size_t)a.N * a.IH * a.IW * a.Cin * 4);
-    const unsigned w_bytes = (unsigned)((size_t)a.Cout * a.K * 4);
-    hipLaunchKernelGGL((conv_gather_dma_kernel<BM, BN, WM, WN, 3>), grid, dim3(256), 0, st, a, in_bytes, w_bytes);
-  }
+  const unsigned in_bytes = (unsigned)((size_t)a.N * a.IH * a.IW * a.Cin * 4);
+  const unsigned w_bytes = (unsigned)((size_t)a.Cout * a.K * 4);
+  if (precision == FCD_PREC_BF16)
+    hipLaunchKernelGGL((conv_gather_dma_kernel<BM, BN, WM, WN, 3, true>), grid, dim3(64 * WM * WN), 0, st, a, in_bytes, w_bytes);
+  else
+    hipLaunchKernelGGL((conv_gather_dma_kernel<BM, BN, WM, WN, 3, false>), grid, dim3(64 * WM * WN), 0, st, a, in_bytes, w_bytes);
   return fcd_check_launch("conv_gather");
 }
 
 template <int BM, int BN, int WM, int WN>
 int launch_wgrad(const WgradArgs& a, int precision, hipStream_t st) {
   dim3 grid(a.tiles_m * a.tiles_n, a.splitk);
-  if (precision == FCD_PREC_BF16) {
-    hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN, true>), grid, dim3(256), 0, st, a);
-  } else {
-    const unsigned gs_bytes = (unsigned)((size_t)a.P * a.OP * 4);
-    const unsigned xb_bytes = (unsigned)((size_t)a.N * a.BH * a.BW * a.IP * 4);
-    hipLaunchKernelGGL((conv_wgrad_dma_kernel<BM, BN, WM, WN, 3>), grid, dim3(256), 0, st, a, gs_bytes, xb_bytes);
-  }
+  const unsigned gs_bytes = (unsigned)((size_t)a.P * a.OP * 4);
+  const unsigned xb_bytes = (unsigned)((size_t)a.N * a.BH * a.BW * a.IP * 4);
+  if (precision == FCD_PREC_BF16)
+    hipLaunchKernelGGL((conv_wgrad_dma_kernel<BM, BN, WM, WN, 3, true>), grid, dim3(64 * WM * WN), 0, st, a, gs_bytes, xb_bytes);
+  else
+    hipLaunchKernelGGL((conv_wgrad_dma_kernel<BM, BN, WM, WN, 3, false>), grid, dim3(64 * WM * WN), 0, st, a, gs_bytes, xb_bytes);
   return fcd_check_launch("conv_wgrad");
 }
 
@@ -998,8 +735,7 @@ int resolve_splitk(const FcdConvDesc* d) {
   gather_tile(d, bm, bn);
   const long M = (long)d->N * d->GH * d->GW;
   const long blocks = (long)fcd_cdiv(M, bm) * fcd_cdiv(d->Cout, bn) * d->nphase;
-  const int bk = d->precision == FCD_PREC_BF16 ? 64 : 32;
-  const int ktiles = fcd_cdiv((long)d->KH * d->KW * d->Cin, bk);
+  const int ktiles = fcd_cdiv((long)d->KH * d->KW * d->Cin, 32);
   // one workgroup per CU already keeps the MFMA pipes busy (the LDS-DMA ring hides the loads);
   // split K only when the tile grid leaves most of the 256 CUs idle
   if (blocks >= 192) return 1;
@@ -1020,13 +756,13 @@ void fill_gather_args(const FcdConvDesc* d, GatherArgs& a) {
     a.ooff_h[i] = d->ooff_h[i]; a.ooff_w[i] = d->ooff_w[i];
   }
   a.M = d->N * d->GH * d->GW;
-  const int bk = d->precision == FCD_PREC_BF16 ? 64 : 32;
-  a.ktiles = fcd_cdiv(a.K, bk);
+  a.ktiles = fcd_cdiv(a.K, 32);
   a.ktiles_per_split = fcd_cdiv(a.ktiles, a.splitk);
   a.splitk = fcd_cdiv(a.ktiles, a.ktiles_per_split);   // no empty splits
   a.w_phase_stride = (long)d->Cout * a.K;
   a.act_slope = d->act_slope; a.mask_slope = d->mask_slope;
-  a.dbg = getenv("FCD_DBG") ? atoi(getenv("FCD_DBG")) : 0;
+  a.tap_inner = (d->Cin % 32 == 0 && d->KH * d->KW > 1) ? 1 : 0;
+
 }
 
 }  // namespace
@@ -1060,10 +796,10 @@ extern "C" int fcd_conv_gather(const FcdConvDesc* d, const float* in, const floa
   a.tiles_m = fcd_cdiv(a.M, bm);
   a.tiles_n = fcd_cdiv(d->Cout, bn);
   if (bm == 128 && bn == 32) rc = launch_gather<128, 32, 4, 1>(a, d->precision, st);
-  else if (bm == 128 && bn == 64) rc = launch_gather<128, 64, 2, 2>(a, d->precision, st);
-  else if (bm == 64 && bn == 128) rc = launch_gather<64, 128, 2, 2>(a, d->precision, st);
+  else if (bm == 128 && bn == 64) rc = launch_gather<128, 64, 4, 2>(a, d->precision, st);
+  else if (bm == 64 && bn == 128) rc = launch_gather<64, 128, 2, 4>(a, d->precision, st);
   else if (bm == 64 && bn == 64) rc = launch_gather<64, 64, 2, 2>(a, d->precision, st);
-  else if (bm == 128 && bn == 128) rc = launch_gather<128, 128, 2, 2>(a, d->precision, st);
+  else if (bm == 128 && bn == 128) rc = launch_gather<128, 128, 2, 4>(a, d->precision, st);
   else { fcd_set_error("conv: no %dx%d tile", bm, bn); return FCD_EINVAL; }
   if (rc) return rc;
   if (a.splitk > 1) {
@@ -1136,10 +872,10 @@ extern "C" int fcd_conv_wgrad(const FcdWgradDesc* d, const float* gsmall, const 
     rc = launch_wgrad<32, 128, 1, 4>(a, d->precision, st);
   } else if (d->O <= 64) {
     a.tiles_m = fcd_cdiv(d->O, 64); a.tiles_n = fcd_cdiv(a.ND, 128);
-    rc = launch_wgrad<64, 128, 2, 2>(a, d->precision, st);
+    rc = launch_wgrad<64, 128, 2, 4>(a, d->precision, st);
   } else {
     a.tiles_m = fcd_cdiv(d->O, 128); a.tiles_n = fcd_cdiv(a.ND, 128);
-    rc = launch_wgrad<128, 128, 2, 2>(a, d->precision, st);
+    rc = launch_wgrad<128, 128, 2, 4>(a, d->precision, st);
   }
   if (rc) return rc;
   const long total = (long)d->O * d->I * d->KH * d->KW;

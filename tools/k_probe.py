@@ -1,5 +1,5 @@
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from fcd_amd import _lib as L, ops
 dev = torch.device('cuda:0')
 n, h, w = 16, 32, 32

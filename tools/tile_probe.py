@@ -1,5 +1,5 @@
 import os, sys, torch, subprocess, json
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def run(prec):
     from fcd_amd import _lib as L, ops
     dev = torch.device('cuda:0')
