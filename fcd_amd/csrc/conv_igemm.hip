@@ -82,19 +82,29 @@ struct WgradArgs {
   int P, ND, splitk, ktiles, ktiles_per_split, tiles_m, tiles_n, accumulate;
 };
 
-// slabs [splitk][O][KH*KW*IP] -> parameter layout [O][I][KH][KW]
+// slabs [splitk][O][KH*KW*IP] -> parameter layout [O][I][KH][KW].  One block per (o, 64 input
+// channels): slab rows are read along i (coalesced), summed over the splits in a fixed order,
+// transposed through LDS and written as one contiguous run of 64*taps floats.
+constexpr int WR_IC = 64;
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs p) {
-  const int taps = p.KH * p.KW;
-  const long total = (long)p.O * p.I * taps;
-  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-    // read-coalesced order: idx -> (o, tap, i)
-    const int i = (int)(idx % p.I);
-    const long t2 = idx / p.I;
-    const int tap = (int)(t2 % taps), o = (int)(t2 / taps);
-    float v = 0.f;
-    for (int s = 0; s < p.splitk; ++s) v += p.slab[((long)s * p.O + o) * p.ND + tap * p.IP + i];
-    const long d = ((long)o * p.I + i) * taps + tap;
-    p.dw[d] = p.accumulate ? p.dw[d] + v : v;
+  extern __shared__ float wr_tile[];   // [WR_IC][taps | 1] (odd row stride: no bank conflicts)
+  const int taps = p.KH * p.KW, tp = taps | 1;
+  const int ichunks = (p.I + WR_IC - 1) / WR_IC;
+  const int o = blockIdx.x / ichunks, i0 = (blockIdx.x % ichunks) * WR_IC;
+  const int ni = min(WR_IC, p.I - i0);
+  for (int e = threadIdx.x; e < taps * WR_IC; e += 256) {
+    const int il = e % WR_IC, tap = e / WR_IC;
+    if (il < ni) {
+      float v = 0.f;
+      for (int s = 0; s < p.splitk; ++s) v += p.slab[((long)s * p.O + o) * p.ND + tap * p.IP + i0 + il];
+      wr_tile[il * tp + tap] = v;
+    }
+  }
+  __syncthreads();
+  float* __restrict__ dst = p.dw + ((long)o * p.I + i0) * taps;
+  for (int e = threadIdx.x; e < ni * taps; e += 256) {
+    const float v = wr_tile[(e / taps) * tp + e % taps];
+    dst[e] = p.accumulate ? dst[e] + v : v;
   }
 }
 
@@ -172,9 +182,13 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
-template <int BM, int BN, int WM, int WN, int S, bool BF16>
+// N16: the output-channel tile is 16 wide (v_mfma_f32_16x16x4_f32) for the 10/12-channel image
+// layers; the B stage keeps its 32-row LDS slot, rows 16.. are loaded as zeros and never read.
+template <int BM, int BN, int WM, int WN, int S, bool BF16, bool N16 = false>
 __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const GatherArgs p, const unsigned in_bytes,
                                                                        const unsigned w_bytes) {
+  static_assert(!N16 || (BN == 32 && WN == 1 && !BF16), "N16 shape");
+  constexpr int BNC = N16 ? 16 : BN;            // output channels this block computes
   constexpr int NW = WM * WN, NT = 64 * NW;     // 4 waves (one per SIMD) or 8 (two per SIMD)
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
@@ -235,8 +249,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
   unsigned b_base[BL];
 #pragma unroll
   for (int i = 0; i < BL; ++i) {
-    const int co = tn * BN + rl + RPI * i;
-    b_base[i] = co < p.Cout ? (unsigned)(co * p.K * 4) : OOB;
+    const int co = tn * BNC + rl + RPI * i;
+    b_base[i] = (co < p.Cout && rl + RPI * i < BNC) ? (unsigned)(co * p.K * 4) : OOB;
   }
 
   const int kt0 = ks * p.ktiles_per_split;
@@ -305,8 +319,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  constexpr int TM16 = WTM / 16;
+  f32x4 acc16[TM16];
+#pragma unroll
+  for (int i = 0; i < TM16; ++i) acc16[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int lr = lane & 31, lh = lane >> 5;
+  const int lr16 = lane & 15, lg = lane >> 4;
 
 #pragma unroll
   for (int s = 0; s < S - 1; ++s) {
@@ -325,7 +344,33 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
     issue_prepare(nstage, it + S - 1 < nk);
     const float4* As = smem + stage * STAGE;
     const float4* Bs = As + BM * 8;
-    if constexpr (BF16) {
+    if constexpr (N16) {
+      // 16x16x4 MFMAs: lane group g = lane>>4 of round j reads chunk 4j+g; element e of the
+      // chunk feeds MFMA e (the k permutation is the same for A and B)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int c = 4 * j + lg;
+        float4 af[TM16];
+#pragma unroll
+        for (int mi = 0; mi < TM16; ++mi) {
+          const int r = wm * WTM + mi * 16 + lr16;
+          af[mi] = As[r * 8 + (c ^ ((r >> 1) & 7))];
+        }
+        const float4 b = Bs[lr16 * 8 + (c ^ ((lr16 >> 1) & 7))];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int mi = 0; mi < TM16; ++mi) {
+            const float av = e == 0 ? af[mi].x : e == 1 ? af[mi].y : e == 2 ? af[mi].z : af[mi].w;
+            const float bv = e == 0 ? b.x : e == 1 ? b.y : e == 2 ? b.z : b.w;
+            acc16[mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc16[mi], 0, 0, 0);
+            const int g = (j * 4 + e) * TM16 + mi;
+#pragma unroll
+            for (int q = 0; q < ND; ++q)
+              if (q * (8 * TM16) / ND == g) issue_one(q);
+          }
+      }
+    } else if constexpr (BF16) {
       // bf16 MFMA on the same fp32 LDS image: lane half h of k16-step s owns k = 16s + 8h .. +7
       // (two 16-byte chunks), rounded to bf16 in registers (v_cvt_pk_bf16_f32)
 #pragma unroll
@@ -406,6 +451,30 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
   // loads of a 32x32 tile are issued together so that their latencies overlap
   float* __restrict__ dst = p.splitk > 1 ? p.slab + (long)blockIdx.y * p.M * p.CoutP : p.out;
   const bool fin = p.splitk == 1;
+  if constexpr (N16) {
+    // D[row = 4*(lane>>4) + r][col = lane&15]
+    const int co = tn * 16 + lr16;
+    if (co >= p.CoutP) return;
+    const bool cok = co < p.Cout;
+    const float bs = (fin && p.bias && cok) ? p.bias[co] : 0.f;
+#pragma unroll
+    for (int mi = 0; mi < TM16; ++mi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long off = rowoff[wm * WTM + mi * 16 + 4 * lg + r];
+        if (off < 0) continue;
+        float v = acc16[mi][r];
+        if (fin) {
+          v += bs;
+          v = v > 0.f ? v : v * p.act_slope;
+          if (p.mask) v *= p.mask[off + co] > 0.f ? 1.f : p.mask_slope;
+          if (p.res) v += p.res[off + co];
+          if (!cok) v = 0.f;
+        }
+        dst[off + co] = v;
+      }
+    return;
+  }
 #pragma unroll
   for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
@@ -453,9 +522,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
 
 // Weight gradient, fp32, LDS-DMA ring.  LDS tiles are [32 pixels][BM | BN] floats, unpadded (one
 // DMA instruction of a wave writes 1 KiB = 256/BM consecutive pixel rows).
-template <int BM, int BN, int WM, int WN, int S, bool BF16>
+// M16: at most 16 output channels (v_mfma_f32_16x16x4_f32 tiles; the A stage keeps its 32-column
+// LDS slot, only columns 0..15 are read).
+template <int BM, int BN, int WM, int WN, int S, bool BF16, bool M16 = false>
 __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_dma_kernel(const WgradArgs p, const unsigned gs_bytes,
                                                                       const unsigned xb_bytes) {
+  static_assert(!M16 || (BM == 32 && WM == 1 && !BF16), "M16 shape");
   constexpr int NW = WM * WN;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
@@ -482,7 +554,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_dma_kernel(const Wgra
   const int nk = kt1 - kt0;
 
   // A (gs): lane -> (pixel row within the instruction, 4 columns)
-  const int a_row = lane / (BM / 4), a_col = (lane % (BM / 4)) * 4;
+  // M16 rotates the columns of LDS row kq (by 16*((kq>>1)&1) in A, 16*(kq&3) in B) so that the
+  // four 16-lane groups of a fragment read, which sit in four consecutive rows, hit distinct banks;
+  // the rotation is applied here, to the source column a lane fetches.
+  const int a_row = lane / (BM / 4);
+  const int a_col = M16 ? (((lane % (BM / 4)) * 4 - 16 * ((a_row >> 1) & 1)) & (BM - 1)) : (lane % (BM / 4)) * 4;
   const int o0 = tm * BM + a_col;
   const bool a_colok = o0 < p.OP;
   int a_px[AL];
@@ -490,7 +566,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_dma_kernel(const Wgra
   for (int i = 0; i < AL; ++i) a_px[i] = kt0 * 32 + (i * NW + wave) * ARPI + a_row;
 
   // B (xb gathered at this lane's tap): column -> (tap, ci)
-  const int b_row = lane / (BN / 4), b_col = (lane % (BN / 4)) * 4;
+  const int b_row = lane / (BN / 4);
+  const int b_col = M16 ? (((lane % (BN / 4)) * 4 - 16 * ((2 * wave + b_row) & 3)) & (BN - 1)) : (lane % (BN / 4)) * 4;
   const int nd = tn * BN + b_col;
   const bool b_colok = nd < p.ND;
   const int tap = nd / p.IP, ci = nd - tap * p.IP;
@@ -542,7 +619,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_dma_kernel(const Wgra
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  f32x4 acc16[WTN / 16];
+#pragma unroll
+  for (int i = 0; i < WTN / 16; ++i) acc16[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
   const int lr = lane & 31, lh = lane >> 5;
+  const int lr16 = lane & 15, lg = lane >> 4;
 #pragma unroll
   for (int s = 0; s < S - 1; ++s) {
     issue_prepare(s, s < nk);
@@ -557,7 +639,29 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_dma_kernel(const Wgra
     issue_prepare(nstage, it + S - 1 < nk);
     const float* As = smem + stage * STAGE;
     const float* Bs = As + 32 * BM;
-    if constexpr (BF16) {
+    if constexpr (M16) {
+      // 16x16x4 MFMAs: lane group g = lane>>4 owns pixel 4*kk + g of k-step kk
+      constexpr int TN16 = WTN / 16;
+      float af[3], bf[3][TN16];
+      auto read16 = [&](int kk, float& a, float* b) {
+        const int kq = 4 * kk + lg;
+        a = As[kq * BM + ((lr16 + 16 * (lg >> 1)) & (BM - 1))];
+#pragma unroll
+        for (int ni = 0; ni < TN16; ++ni) b[ni] = Bs[kq * BN + ((wn * WTN + ni * 16 + 16 * lg) & (BN - 1)) + lr16];
+      };
+      read16(0, af[0], bf[0]);
+      read16(1, af[1], bf[1]);
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        if (kk + 2 < 8) read16(kk + 2, af[(kk + 2) % 3], bf[(kk + 2) % 3]);
+#pragma unroll
+        for (int ni = 0; ni < TN16; ++ni)
+          acc16[ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[kk % 3], bf[kk % 3][ni], acc16[ni], 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < ND; ++q)
+          if (q * 8 / ND == kk) issue_one(q);
+      }
+    } else if constexpr (BF16) {
       // k = pixel: lane half h of k16-step s owns pixels 16s + 8h .. +7 of its column
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
@@ -617,6 +721,20 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_dma_kernel(const Wgra
   }
 
   float* __restrict__ dst = p.slab + (long)ks * p.O * p.ND;
+  if constexpr (M16) {
+    // D[o = 4*(lane>>4) + r][col = lane&15]
+#pragma unroll
+    for (int ni = 0; ni < WTN / 16; ++ni) {
+      const int col = tn * BN + wn * WTN + ni * 16 + lr16;
+      if (col >= p.ND) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int o = 4 * lg + r;
+        if (o < p.O) dst[(long)o * p.ND + col] = acc16[ni][r];
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
@@ -722,7 +840,8 @@ void gather_tile(const FcdConvDesc* d, int& bm, int& bn) {
   if (const char* e = getenv("FCD_TILE")) {   // tuning aid: "128x64" etc.
     if (sscanf(e, "%dx%d", &bm, &bn) == 2) return;
   }
-  if (d->Cout <= 32) { bm = 128; bn = 32; }
+  if (d->Cout <= 16 && d->precision == FCD_PREC_F32) { bm = 128; bn = 16; }   // 16-wide MFMA tiles
+  else if (d->Cout <= 32) { bm = 128; bn = 32; }
   else if (d->Cout <= 64) { bm = 128; bn = 64; }
   else if (M <= 64) { bm = 64; bn = 128; }
   else { bm = 128; bn = 128; }
@@ -795,7 +914,12 @@ extern "C" int fcd_conv_gather(const FcdConvDesc* d, const float* in, const floa
   gather_tile(d, bm, bn);
   a.tiles_m = fcd_cdiv(a.M, bm);
   a.tiles_n = fcd_cdiv(d->Cout, bn);
-  if (bm == 128 && bn == 32) rc = launch_gather<128, 32, 4, 1>(a, d->precision, st);
+  if (bm == 128 && bn == 16 && d->precision == FCD_PREC_F32) {
+    dim3 grid(a.tiles_m * a.tiles_n, a.nphase * a.splitk);
+    hipLaunchKernelGGL((conv_gather_dma_kernel<128, 32, 4, 1, 3, false, true>), grid, dim3(256), 0, st, a,
+                       (unsigned)((size_t)a.N * a.IH * a.IW * a.Cin * 4), (unsigned)((size_t)a.Cout * a.K * 4));
+    rc = fcd_check_launch("conv_gather");
+  } else if (bm == 128 && bn == 32) rc = launch_gather<128, 32, 4, 1>(a, d->precision, st);
   else if (bm == 128 && bn == 64) rc = launch_gather<128, 64, 4, 2>(a, d->precision, st);
   else if (bm == 64 && bn == 128) rc = launch_gather<64, 128, 2, 4>(a, d->precision, st);
   else if (bm == 64 && bn == 64) rc = launch_gather<64, 64, 2, 2>(a, d->precision, st);
@@ -867,7 +991,13 @@ extern "C" int fcd_conv_wgrad(const FcdWgradDesc* d, const float* gsmall, const 
   a.splitk = fcd_cdiv(a.ktiles, a.ktiles_per_split);
   a.accumulate = d->accumulate;
   hipStream_t st = fcd_stream(stream);
-  if (d->O <= 32) {
+  if (d->O <= 16 && d->precision == FCD_PREC_F32) {
+    a.tiles_m = 1; a.tiles_n = fcd_cdiv(a.ND, 128);
+    dim3 grid(a.tiles_n, a.splitk);
+    hipLaunchKernelGGL((conv_wgrad_dma_kernel<32, 128, 1, 4, 3, false, true>), grid, dim3(256), 0, st, a,
+                       (unsigned)((size_t)a.P * a.OP * 4), (unsigned)((size_t)a.N * a.BH * a.BW * a.IP * 4));
+    rc = fcd_check_launch("conv_wgrad");
+  } else if (d->O <= 32) {
     a.tiles_m = fcd_cdiv(d->O, 32); a.tiles_n = fcd_cdiv(a.ND, 128);
     rc = launch_wgrad<32, 128, 1, 4>(a, d->precision, st);
   } else if (d->O <= 64) {
@@ -878,9 +1008,8 @@ extern "C" int fcd_conv_wgrad(const FcdWgradDesc* d, const float* gsmall, const 
     rc = launch_wgrad<128, 128, 2, 4>(a, d->precision, st);
   }
   if (rc) return rc;
-  const long total = (long)d->O * d->I * d->KH * d->KW;
-  const int blocks = (int)std::min<long>(fcd_cdiv(total, 256), 4096);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, a);
+  const int blocks = d->O * fcd_cdiv(d->I, WR_IC);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), (size_t)WR_IC * (d->KH * d->KW | 1) * sizeof(float), st, a);
   return fcd_check_launch("wgrad_reduce");
 }
 

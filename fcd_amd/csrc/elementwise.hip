@@ -40,6 +40,18 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restri
   }
 }
 
+// many channels, few pixels (the discriminator's feature map): one thread per output element
+__global__ __launch_bounds__(256) void nhwc_to_nchw_wide_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                                int accumulate, int N, int C, int CP, long HW) {
+  const long total = (long)N * C * HW;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const long px = idx % HW, nk = idx / HW;
+    const long k = nk % C, n = nk / C;
+    const float v = x[(n * HW + px) * CP + k];
+    out[idx] = accumulate ? out[idx] + v : v;
+  }
+}
+
 // ---------------------------------------------------------------- G epilogue -----------
 __global__ __launch_bounds__(256) void g_epilogue_fwd_kernel(const float* __restrict__ delta, const float* __restrict__ x,
                                                              float* __restrict__ xf, int N, int C, int CP, long HW) {
@@ -358,8 +370,12 @@ extern "C" int fcd_nchw_to_nhwc(const float* x, float* out, int N, int C, int CP
 extern "C" int fcd_nhwc_to_nchw(const float* x, float* out, int accumulate, int N, int C, int CP, int H, int W,
                                 void* stream) {
   FCD_REQUIRE(x && out && N > 0 && C > 0 && CP >= C && H > 0 && W > 0, "nhwc_to_nchw: bad arguments");
-  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for((size_t)N * H * W)), dim3(256), 0, fcd_stream(stream), x, out,
-                     accumulate, N, C, CP, (long)H * W);
+  if (C > 16)
+    hipLaunchKernelGGL(nhwc_to_nchw_wide_kernel, dim3(grid_for((size_t)N * C * H * W)), dim3(256), 0, fcd_stream(stream), x,
+                       out, accumulate, N, C, CP, (long)H * W);
+  else
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for((size_t)N * H * W)), dim3(256), 0, fcd_stream(stream), x, out,
+                       accumulate, N, C, CP, (long)H * W);
   return fcd_check_launch("nhwc_to_nchw");
 }
 
