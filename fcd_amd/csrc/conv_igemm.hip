@@ -92,13 +92,21 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs p) {
   const int ichunks = (p.I + WR_IC - 1) / WR_IC;
   const int o = blockIdx.x / ichunks, i0 = (blockIdx.x % ichunks) * WR_IC;
   const int ni = min(WR_IC, p.I - i0);
-  for (int e = threadIdx.x; e < taps * WR_IC; e += 256) {
-    const int il = e % WR_IC, tap = e / WR_IC;
-    if (il < ni) {
-      float v = 0.f;
-      for (int s = 0; s < p.splitk; ++s) v += p.slab[((long)s * p.O + o) * p.ND + tap * p.IP + i0 + il];
-      wr_tile[il * tp + tap] = v;
+  const long sstride = (long)p.O * p.ND;
+  for (int e = threadIdx.x; e < taps * ni; e += 256) {
+    const int il = e % ni, tap = e / ni;
+    const float* src = p.slab + (long)o * p.ND + tap * p.IP + i0 + il;
+    float v = 0.f;
+    int s = 0;
+    for (; s + 8 <= p.splitk; s += 8) {   // eight loads in flight, summed in split order
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = src[(s + u) * sstride];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v += t[u];
     }
+    for (; s < p.splitk; ++s) v += src[s * sstride];
+    wr_tile[il * tp + tap] = v;
   }
   __syncthreads();
   float* __restrict__ dst = p.dw + ((long)o * p.I + i0) * taps;
@@ -541,9 +549,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_dma_kernel(const Wgra
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int tn = bid % p.tiles_n, tm = bid / p.tiles_n;
-  const int ks = blockIdx.y;
+  // XCD-aware order over (split, tile) together: an XCD gets a contiguous run of ids, i.e. (about)
+  // all tiles of one pixel range, whose gs/xb rows then stay in that XCD's L2 across the tiles
+  const int ntile = p.tiles_m * p.tiles_n;
+  const int bid = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+  const int ks = bid / ntile, tile = bid - ks * ntile;
+  const int tn = tile % p.tiles_n, tm = tile / p.tiles_n;
 
   const i32x4 rgs = make_rsrc(p.gs, gs_bytes);
   const i32x4 rxb = make_rsrc(p.xb, xb_bytes);
