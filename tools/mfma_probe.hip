@@ -15,6 +15,9 @@ __device__ __forceinline__ void ld16(const i32x4 rsrc, const unsigned voff) {
   i32x4 d;
   asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(d) : "v"(voff), "s"(rsrc) : "memory");
 }
+__device__ __forceinline__ void dma16_nom0(const i32x4 rsrc, const unsigned voff) {
+  asm volatile("buffer_load_dwordx4 %0, %1, 0 offen lds" : : "v"(voff), "s"(rsrc) : "memory");
+}
 __device__ __forceinline__ void dma16(const i32x4 rsrc, const unsigned voff, const unsigned lds_addr) {
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
@@ -28,7 +31,7 @@ __global__ __launch_bounds__(THREADS) void probe(float* out, int tiles, const fl
   if ((MODE & 8) && tid == 0) stamps[2048 + blockIdx.x * 4] = wall_clock64();
   for (int i = tid; i < 3 * 2048; i += THREADS) smem[i] = make_float4(i * 1e-6f, 1.f, 0.5f, 0.25f);
   __syncthreads();
-  constexpr int NT = THREADS == 256 ? 4 : 2;   // 32x32 accumulators per wave
+  constexpr int NT = THREADS == 256 ? 4 : THREADS == 512 ? 2 : 1;   // 32x32 accumulators per wave
   f32x16 acc[NT];
   for (int t = 0; t < NT; ++t)
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
@@ -38,7 +41,7 @@ __global__ __launch_bounds__(THREADS) void probe(float* out, int tiles, const fl
   const i32x4 rs = make_rsrc(src, src_bytes);
   const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)smem;
   unsigned goff = (unsigned)((blockIdx.x * 128 + 8 * wave + (lane >> 3)) * 1024 + (lane & 7) * 16);   // row-major [rows][256 floats]
-  constexpr int ND = THREADS == 256 ? 8 : 4;
+  constexpr int ND = THREADS == 256 ? 8 : THREADS == 512 ? 4 : 2;
   if (MODE & 4) {
     for (int s = 0; s < 2; ++s) {
       for (int q = 0; q < ND; ++q) dma16(rs, goff + q * 32 * 1024, lds0 + (s * 2048 + (wave * ND + q) * 64) * 16);
@@ -46,9 +49,12 @@ __global__ __launch_bounds__(THREADS) void probe(float* out, int tiles, const fl
     }
   }
   int nstage = 2;
+  if (MODE & 256) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" : : "s"(lds0 + wave * 1024) : "memory");
   for (int it = 0; it < tiles; ++it) {
     if ((MODE & 4) && !(MODE & 32)) {
-      if (ND == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      if (ND == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (ND == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     }
     if (MODE & 2) __builtin_amdgcn_s_barrier();
     if ((MODE & 8) && lane == 0 && (blockIdx.x == 0 || blockIdx.x == 100) && wave == 0)
@@ -72,14 +78,15 @@ __global__ __launch_bounds__(THREADS) void probe(float* out, int tiles, const fl
         acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, y0, acc[0], 0, 0, 0);
         if ((MODE & 4) && !(MODE & 16) && (j * 4 + e) % (16 / ND) == 1) {
           const int q = (j * 4 + e) / (16 / ND);
-          if (MODE & 64) ld16(rs, (goff + q * 32 * 1024) % src_bytes);
+          if (MODE & 256) dma16_nom0(rs, (goff + q * 32 * 1024) % src_bytes);
+          else if (MODE & 64) ld16(rs, (goff + q * 32 * 1024) % src_bytes);
           else dma16(rs, (goff + q * 32 * 1024) % src_bytes, lds0 + (nstage * 2048 + (wave * ND + q) * 64) * 16);
         }
         if ((MODE & 4) && (MODE & 16) && j == 0 && e == 0) {
 #pragma unroll
           for (int q = 0; q < ND; ++q) dma16(rs, (goff + q * 32 * 1024) % src_bytes, lds0 + (nstage * 2048 + (wave * ND + q) * 64) * 16);
         }
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, y0, acc[1], 0, 0, 0);
+        if (NT >= 2) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, y0, acc[1], 0, 0, 0);
         if (NT == 4) {
           acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, y1, acc[2], 0, 0, 0);
           acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, y1, acc[3], 0, 0, 0);
@@ -194,7 +201,7 @@ void run(const char* name, float* out, int blocks, int tiles, const float* src =
   hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
   const double us = ms * 1e3 / 20;
-  const double mfma = (double)blocks * (THREADS / 64) * tiles * (THREADS == 256 ? 64 : 32);
+  const double mfma = (double)blocks * (THREADS / 64) * tiles * (THREADS == 256 ? 64 : THREADS == 512 ? 32 : 16);
   printf("%-34s blocks %4d tiles %4d  %8.1f us  %6.1f TF  cycles/MFMA/SIMD@2.4GHz %.1f\n", name, blocks, tiles, us,
          mfma * 4096 * 1e-6 / us, us * 1e-6 * 2.4e9 / (mfma / (256.0 * 4)));
 }
@@ -216,12 +223,16 @@ int main() {
     run_ws<4>("specialised: 4 MFMA + 4 DMA waves", out, 256, tiles, src, sb);
     run_ws<2>("specialised: 4 MFMA + 2 DMA waves", out, 256, tiles, src, sb);
     run_ws<1>("specialised: 4 MFMA + 1 DMA wave", out, 256, tiles, src, sb);
+    run<7 + 256, 256>("  .. DMA without M0 traffic", out, 256, tiles, src, sb);
+    run<7 + 256, 512>("  .. DMA without M0, 8 w/block", out, 256, tiles, src, sb);
     run<7 + 16, 256>("  .. DMAs issued together", out, 256, tiles, src, sb);
     run<7 + 32, 256>("  .. no vmcnt wait", out, 256, tiles, src, sb);
     run<7 + 64, 256>("  .. loads to VGPR not LDS", out, 256, tiles, src, sb);
     run<7 + 64 + 32, 256>("  .. loads to VGPR, no vmcnt", out, 256, tiles, src, sb);
     run<5, 256>("mfma+lds+DMA no barrier, 4 w/CU", out, 256, tiles, src, sb);
     run<7, 512>("mfma+lds+barrier+DMA, 8 w/block", out, 256, tiles, src, sb);
+    run<7, 1024>("mfma+lds+barrier+DMA, 16 w/block", out, 256, tiles, src, sb);
+    run<3, 1024>("mfma+lds+barrier, 16 w/block", out, 256, tiles, src, sb);
     run<0, 256>("mfma only, 4 waves/CU", out, 256, tiles);
     run<1, 256>("mfma + lds reads, 4 waves/CU", out, 256, tiles);
     run<3, 256>("mfma + lds + barrier, 4 waves/CU", out, 256, tiles);
