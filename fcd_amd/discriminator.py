@@ -16,7 +16,6 @@ of elementary ops.
 from __future__ import annotations
 
 import contextlib
-import threading
 from typing import List, Optional
 
 import numpy as np
@@ -25,10 +24,18 @@ import torch.nn as nn
 
 from . import _lib as L
 from . import ops
+from .arena import grad_sink
 from .generator import ConvParams, _act_slope
 from .ops import ConvGeom
 
-_state = threading.local()
+class _State:
+    """Process-wide on purpose, not thread-local: autograd runs a CUDA graph's backward nodes on
+    its own worker thread, which must see the flag the calling thread set around
+    ``torch.autograd.grad`` (the call blocks until that backward is done)."""
+    input_only = False
+
+
+_state = _State()
 
 
 @contextlib.contextmanager
@@ -155,13 +162,17 @@ class _DBackwardFn(torch.autograd.Function):
             ops.head_dgrad(g_src, mod.conv1.packed("fwd", mod._g1), gz, top, slope, False, 3, 1)
             first = False
             if want_params:
-                grads[2 * nl] = ops.head_wgrad(g_src, top, mod._g1.I, 3, 1)
+                sink = grad_sink(mod.conv1.weight, True)
+                dw = ops.head_wgrad(g_src, top, mod._g1.I, 3, 1, dw=sink, accumulate=sink is not None)
+                grads[2 * nl] = None if sink is not None else dw
         if g_cls is not None:
             g_cls4 = g_cls.contiguous().view(n, mod.c_dim, 1, 1)
             ops.head_dgrad(g_cls4, mod.conv2.packed("fwd", mod._g2), gz, top, slope, not first, mod._g2.k, 0)
             first = False
             if want_params:
-                grads[2 * nl + 1] = ops.head_wgrad(g_cls4, top, mod._g2.I, mod._g2.k, 0)
+                sink = grad_sink(mod.conv2.weight, True)
+                dw = ops.head_wgrad(g_cls4, top, mod._g2.I, mod._g2.k, 0, dw=sink, accumulate=sink is not None)
+                grads[2 * nl + 1] = None if sink is not None else dw
         if first:
             gz.zero_()
         gzs = [None] * nl          # gzs[l] = masked gradient at layer l's pre-activation
@@ -177,10 +188,15 @@ class _DBackwardFn(torch.autograd.Function):
             g = mod._geoms[li]
             a_in = acts[li]
             if want_params:
-                wd = g.wgrad_desc(n, a_in.shape[1], a_in.shape[2], precision=prec)
-                grads[2 * li] = ops.conv_wgrad(wd, gz, a_in)
-                bs = ops.colsum(gz.numel() // gz.shape[3], gz, gz.shape[3])
-                grads[2 * li + 1] = bs if gz.shape[3] == g.O else bs[: g.O].contiguous()
+                cv = mod._convs[li]
+                sink = grad_sink(cv.weight, True)
+                wd = g.wgrad_desc(n, a_in.shape[1], a_in.shape[2], precision=prec, accumulate=sink is not None)
+                dw = ops.conv_wgrad(wd, gz, a_in, dw=sink)
+                grads[2 * li] = None if sink is not None else dw
+                bsink = grad_sink(cv.bias, gz.shape[3] == g.O)
+                bs = ops.colsum(gz.numel() // gz.shape[3], gz, gz.shape[3], out=bsink, accumulate=bsink is not None)
+                if bsink is None:
+                    grads[2 * li + 1] = bs if gz.shape[3] == g.O else bs[: g.O].contiguous()
             if li == 0:
                 if want_x:
                     d = g.adj_desc(n, gz.shape[1], gz.shape[2], precision=prec)
@@ -214,16 +230,23 @@ class _DBackwardFn(torch.autograd.Function):
         for li in range(nl):
             g = mod._geoms[li]
             if needs[2 * li]:
-                wd = g.wgrad_desc(n, u.shape[1], u.shape[2], precision=prec)
-                out[2 * li] = ops.conv_wgrad(wd, gzs[li], u)
-            if needs[2 * li + 1]:
+                sink = grad_sink(mod._convs[li].weight, True)
+                wd = g.wgrad_desc(n, u.shape[1], u.shape[2], precision=prec, accumulate=sink is not None)
+                dw = ops.conv_wgrad(wd, gzs[li], u, dw=sink)
+                out[2 * li] = None if sink is not None else dw
+            if needs[2 * li + 1] and grad_sink(mod._convs[li].bias, True) is None:
                 out[2 * li + 1] = torch.zeros_like(mod._convs[li].bias)
             d = g.fwd_desc(n, u.shape[1], u.shape[2], precision=prec, mask_slope=slope)
             u = ops.conv_gather(d, u, mod._convs[li].packed("fwd", g), mask=acts[li + 1])
         if needs[2 * nl] and ctx.g_src is not None:
-            out[2 * nl] = ops.head_wgrad(ctx.g_src, u, mod._g1.I, 3, 1)
+            sink = grad_sink(mod.conv1.weight, True)
+            dw = ops.head_wgrad(ctx.g_src, u, mod._g1.I, 3, 1, dw=sink, accumulate=sink is not None)
+            out[2 * nl] = None if sink is not None else dw
         if needs[2 * nl + 1] and ctx.g_cls is not None:
-            out[2 * nl + 1] = ops.head_wgrad(ctx.g_cls.contiguous().view(n, mod.c_dim, 1, 1), u, mod._g2.I, mod._g2.k, 0)
+            sink = grad_sink(mod.conv2.weight, True)
+            dw = ops.head_wgrad(ctx.g_cls.contiguous().view(n, mod.c_dim, 1, 1), u, mod._g2.I, mod._g2.k, 0, dw=sink,
+                                accumulate=sink is not None)
+            out[2 * nl + 1] = None if sink is not None else dw
         # d/d g_src, d/d g_cls (linear) are not needed by the GP: grad_outputs is a constant
         ctx.gzs = None
         return (None,) * 8 + tuple(out)

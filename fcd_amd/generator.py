@@ -22,6 +22,7 @@ import torch.nn as nn
 
 from . import _lib as L
 from . import ops
+from .arena import grad_sink
 from .ops import ConvGeom
 
 
@@ -253,23 +254,30 @@ class _GeneratorFn(torch.autograd.Function):
                 if ly.res_from is not None:
                     pending_res[li + 1 + ly.res_from] = g      # h_out = h_in + IN(..): pass g to h_in too
                 want_aff = needs[p0 + 1] or needs[p0 + 2]
+                sg, sb = grad_sink(ly.norm.weight, needs[p0 + 1]), grad_sink(ly.norm.bias, needs[p0 + 2])
+                direct = want_aff and sg is not None and sb is not None
                 dz, dgam, dbet = ops.instnorm_bwd(g, y if ly.res_from is None else z, z, mean, rstd,
                                                   ly.norm.weight.detach(), ly.act_slope, use_running,
-                                                  want_affine=want_aff)
-                if needs[p0 + 1]:
-                    grads[p0 + 1] = dgam
-                if needs[p0 + 2]:
-                    grads[p0 + 2] = dbet
+                                                  want_affine=want_aff, dgamma=sg if direct else None,
+                                                  dbeta=sb if direct else None, accumulate=direct)
+                if not direct:
+                    if needs[p0 + 1]:
+                        grads[p0 + 1] = dgam
+                    if needs[p0 + 2]:
+                        grads[p0 + 2] = dbet
             else:
                 dz = g
             # weight gradient
             if needs[p0]:
+                sink = grad_sink(ly.conv.weight, True)     # arena-backed: accumulate into p.grad in place
                 if ly.kind == "conv":
-                    wd = gm.wgrad_desc(n, a_in.shape[1], a_in.shape[2], precision=prec)
-                    grads[p0] = ops.conv_wgrad(wd, dz, a_in)
+                    wd = gm.wgrad_desc(n, a_in.shape[1], a_in.shape[2], precision=prec, accumulate=sink is not None)
+                    dw = ops.conv_wgrad(wd, dz, a_in, dw=sink)
                 else:
-                    wd = gm.wgrad_desc(n, dz.shape[1], dz.shape[2], precision=prec)
-                    grads[p0] = ops.conv_wgrad(wd, a_in, dz)
+                    wd = gm.wgrad_desc(n, dz.shape[1], dz.shape[2], precision=prec, accumulate=sink is not None)
+                    dw = ops.conv_wgrad(wd, a_in, dz, dw=sink)
+                if sink is None:
+                    grads[p0] = dw
             # data gradient
             if li == 0:
                 if need_x:

@@ -254,15 +254,21 @@ def instnorm_apply(z, mean, rstd, gamma, beta, act_slope: float, residual=None, 
     return out
 
 
-def instnorm_bwd(gy, y, z, mean, rstd, gamma, act_slope: float, use_running: bool, want_affine: bool = True):
+def instnorm_bwd(gy, y, z, mean, rstd, gamma, act_slope: float, use_running: bool, want_affine: bool = True,
+                 dgamma=None, dbeta=None, accumulate: bool = False):
+    """``dgamma`` / ``dbeta`` given: written (``accumulate``: added to) in place."""
     n, h, w, c = z.shape
     lib = L.load()
     dz = torch.empty_like(z)
-    dgamma = torch.empty_like(gamma) if want_affine else None
-    dbeta = torch.empty_like(gamma) if want_affine else None
+    if want_affine and dgamma is None and dbeta is None:
+        if accumulate:
+            raise RuntimeError("instnorm_bwd: accumulate needs dgamma / dbeta")
+        dgamma = torch.empty_like(gamma)
+        dbeta = torch.empty_like(gamma)
     wp, wn = _ws(lib.fcd_instnorm_workspace_bytes(n, h * w, c), z.device)
     check(lib.fcd_instnorm_bwd(ptr(gy), ptr(y), ptr(z), ptr(mean), ptr(rstd), ptr(gamma), ptr(dz), ptr(dgamma),
-                               ptr(dbeta), 0, n, h * w, c, act_slope, int(use_running), wp, wn, stream()), "instnorm_bwd")
+                               ptr(dbeta), int(accumulate), n, h * w, c, act_slope, int(use_running), wp, wn, stream()),
+          "instnorm_bwd")
     return dz, dgamma, dbeta
 
 

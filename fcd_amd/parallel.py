@@ -65,6 +65,22 @@ class GradSync:
                     v.div_(self.world)
                 grads[i].copy_(v.view_as(grads[i]))
 
+    def allreduce_flat(self, flat: torch.Tensor) -> None:
+        """Average a gradient arena over ranks in place: bucket-sized views of the buffer itself
+        go to the collective, nothing is packed or unpacked."""
+        if self.world == 1 or flat.numel() == 0:
+            return
+        backend = dist.get_backend(self.group)
+        op = dist.ReduceOp.AVG if backend == "nccl" else dist.ReduceOp.SUM
+        work = []
+        for off in range(0, flat.numel(), self.bucket_elems):
+            v = flat[off:off + self.bucket_elems]
+            work.append((dist.all_reduce(v, op=op, group=self.group, async_op=True), v))
+        for w, v in work:
+            w.wait()
+            if op == dist.ReduceOp.SUM:
+                v.div_(self.world)
+
     def broadcast_params(self, modules) -> None:
         """Identical initial weights and buffers on all ranks (DDP does this at construction)."""
         if self.world == 1:

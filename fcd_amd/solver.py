@@ -20,6 +20,7 @@ import torch.nn as nn
 
 from . import _lib as L
 from . import losses, ops
+from .arena import ParamArena
 from .discriminator import Discriminator, input_grad_only
 from .generator import Generator
 
@@ -37,10 +38,17 @@ def default_config(**over) -> Namespace:
 
 
 class FusedAdam(torch.optim.Optimizer):
-    """torch.optim.Adam(lr, betas) semantics (``fcd_solver.py:183,186``) with the HIP update."""
+    """torch.optim.Adam(lr, betas) semantics (``fcd_solver.py:183,186``) with the HIP update.
 
-    def __init__(self, params, lr=1e-4, betas=(0.5, 0.999), eps=1e-8):
+    With an ``arena`` (:class:`fcd_amd.arena.ParamArena` over exactly these parameters) the
+    whole network is updated by ONE launch over the flat buffers; that equals the
+    per-parameter update as long as every parameter receives a gradient in every step it
+    takes part in (true for the FCD losses: a parameter without gradient keeps m = v = 0)."""
+
+    def __init__(self, params, lr=1e-4, betas=(0.5, 0.999), eps=1e-8, arena=None):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self.arena = arena
+        self._flat_state = None
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -48,6 +56,9 @@ class FusedAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        if self.arena is not None and self.arena.intact():
+            self._step_arena()
+            return loss
         for group in self.param_groups:
             b1, b2 = group["betas"]
             for p in group["params"]:
@@ -61,7 +72,25 @@ class FusedAdam(torch.optim.Optimizer):
                 st["step"] += 1
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 ops.adam_step(p, g, st["exp_avg"], st["exp_avg_sq"], group["lr"], b1, b2, group["eps"], st["step"])
+                torch.autograd.graph.increment_version(p)    # raw-pointer update: invalidate packed copies
         return loss
+
+    def _step_arena(self):
+        ar = self.arena
+        group = self.param_groups[0]
+        if self._flat_state is None:
+            m, v = torch.zeros_like(ar.flat), torch.zeros_like(ar.flat)
+            self._flat_state = {"step": 0, "exp_avg": m, "exp_avg_sq": v}
+            for p, off in zip(ar.params, ar.offsets):      # per-parameter views: the usual state_dict layout
+                self.state[p] = {"step": 0, "exp_avg": m[off:off + p.numel()].view(p.shape),
+                                 "exp_avg_sq": v[off:off + p.numel()].view(p.shape)}
+        fs = self._flat_state
+        fs["step"] += 1
+        b1, b2 = group["betas"]
+        ops.adam_step(ar.flat, ar.grad, fs["exp_avg"], fs["exp_avg_sq"], group["lr"], b1, b2, group["eps"], fs["step"])
+        for p in ar.params:
+            self.state[p]["step"] = fs["step"]
+        ar.bump_versions()
 
 
 class FCDSolver(nn.Module):
@@ -90,6 +119,7 @@ class FCDSolver(nn.Module):
         self.build_model()
         self.set_precision(getattr(config, "precision", "fp32"))
         self._opts = None
+        self.arenas = (None, None)
 
     # ---------------------------------------------------------------- model -------------
     def build_model(self):
@@ -109,10 +139,15 @@ class FCDSolver(nn.Module):
     def device(self):
         return next(self.G.parameters()).device
 
-    def configure_optimizers(self):
-        opt_D = FusedAdam(self.D.parameters(), self.d_lr, (self.beta1, self.beta2))
+    def configure_optimizers(self, arenas: bool = False):
+        """``arenas``: move each network's parameters / gradients into flat arenas (see
+        :mod:`fcd_amd.arena`); do it after the final ``.to(device)``."""
+        ar_d = ParamArena(self.D.parameters()) if arenas else None
+        ar_g = ParamArena(self.G.parameters()) if arenas else None
+        self.arenas = (ar_d, ar_g)
+        opt_D = FusedAdam(self.D.parameters(), self.d_lr, (self.beta1, self.beta2), arena=ar_d)
         sched_D = torch.optim.lr_scheduler.ReduceLROnPlateau(opt_D, mode="max", patience=10)
-        opt_G = FusedAdam(self.G.parameters(), self.g_lr, (self.beta1, self.beta2))
+        opt_G = FusedAdam(self.G.parameters(), self.g_lr, (self.beta1, self.beta2), arena=ar_g)
         sched_G = torch.optim.lr_scheduler.ReduceLROnPlateau(opt_G, mode="max", patience=10)
         return ({"optimizer": opt_D, "lr_scheduler": {"scheduler": sched_D, "monitor": "val/F1Score"}},
                 {"optimizer": opt_G, "lr_scheduler": {"scheduler": sched_G, "monitor": "val/F1Score"}})
@@ -204,7 +239,7 @@ class FCDSolver(nn.Module):
     # ---------------------------------------------------------------- training loop body -
     def optimizers(self):
         if self._opts is None:
-            od, og = self.configure_optimizers()
+            od, og = self.configure_optimizers(arenas=self.device.type == "cuda")
             self._opts = (od["optimizer"], og["optimizer"])
         return self._opts
 
@@ -218,11 +253,18 @@ class FCDSolver(nn.Module):
             loss = self.training_step(batch, batch_idx, optimizer_idx)
             if loss is not None:
                 loss.backward()
+                arena = opt.arena if opt.arena is not None and opt.arena.intact() else None
                 if self.grad_sync is not None:
-                    self.grad_sync.allreduce([p for p in mine.parameters() if p.grad is not None])
+                    if arena is not None:
+                        self.grad_sync.allreduce_flat(arena.grad)
+                    else:
+                        self.grad_sync.allreduce([p for p in mine.parameters() if p.grad is not None])
                 if step:
                     opt.step()
-            opt.zero_grad(set_to_none=True)
+            if opt.arena is not None and opt.arena.intact():
+                opt.arena.zero_grad()
+            else:
+                opt.zero_grad(set_to_none=True)
         finally:
             other.requires_grad_(True)
         return loss

@@ -142,3 +142,84 @@ def test_masks_bit_exact_from_same_diff(dev, tiny):
     # away from the threshold the masks equal the reference's
     far = (torch.from_numpy(z["diff_eval"]) - sc["thr"]).abs() > 1e-5
     assert bool((mask.cpu()[far] == torch.from_numpy(z["mask_eval"])[far]).all())
+
+
+def _oracle_two_steps(z, sc, lr):
+    from oracle import fcd_oracle as O
+    gs = {k[2:]: torch.from_numpy(z[k]).clone() for k in z.files if k.startswith("G.")}
+    ds = {k[2:]: torch.from_numpy(z[k]).clone() for k in z.files if k.startswith("D.")}
+    t = lambda k: torch.from_numpy(z[k])
+    batch = (t("x"), t("c_org"), t("c_trg"), t("label_org"), t("label_trg"))
+    alpha = t("alpha")
+    st = {}
+    losses = {}
+    for step in (1, 2):
+        ns = {}
+        _, ld, dg = O.d_step(gs, ds, batch, alpha, new_stats=ns)
+        gs.update(ns)
+        for k, g in dg.items():
+            m, v = st.get(("d", k), (torch.zeros_like(g), torch.zeros_like(g)))
+            ds[k], m, v = O.adam_update(ds[k], g, m, v, step, lr=lr)
+            st[("d", k)] = (m, v)
+        ns = {}
+        _, lg, gg = O.g_step(gs, ds, batch, new_stats=ns)
+        gs.update(ns)
+        for k, g in gg.items():
+            m, v = st.get(("g", k), (torch.zeros_like(g), torch.zeros_like(g)))
+            gs[k], m, v = O.adam_update(gs[k], g, m, v, step, lr=lr)
+            st[("g", k)] = (m, v)
+        losses = {**ld, **lg}
+    return gs, ds, losses
+
+
+def test_two_train_steps_match_oracle(dev, tiny):
+    """Two full train steps (D update, G update, both Adam steps, running statistics) against
+    the CPU oracle: the second step only matches if the first one's updates really reached the
+    kernels (packed weight copies refreshed, arena views intact)."""
+    z, sc = tiny
+    lr = 1e-3
+    s = build(z, sc["cfg"], dev)
+    s.d_lr = s.g_lr = lr
+    s.alpha_override = torch.from_numpy(z["alpha"])
+    b = batch_of(z, dev)
+    for _ in range(2):
+        s.train_step(b, force_g=True)
+    torch.cuda.synchronize()
+    assert all(a is not None and a.intact() for a in s.arenas)
+    gs, ds, losses = _oracle_two_steps(z, sc, lr)
+    for k, v in losses.items():
+        assert abs(float(s.loss_dict[k]) - float(v)) <= 2e-4 * max(1.0, abs(float(v))), (k, float(s.loss_dict[k]), float(v))
+    # Adam's first steps are ~lr*sign(g): an element whose gradient is at rounding level can land
+    # on the other side, so parameters are compared with a bound of a few such elements
+    worst = 0.0
+    for net, sd in ((s.G, gs), (s.D, ds)):
+        for name, t in net.state_dict().items():
+            if not t.is_floating_point():
+                continue
+            worst = max(worst, relerr(t, sd[name]))
+    print("two-step worst state rel-err", worst)
+    assert worst <= 5e-3
+
+
+def test_arena_gradients_match_fixtures(dev, tiny):
+    """Same D-step gradients when the backward kernels accumulate straight into the gradient
+    arena (the training path) instead of going through autograd (the other tests)."""
+    z, sc = tiny
+    s = build(z, sc["cfg"], dev)
+    s.optimizers()                       # creates the arenas
+    assert s.arenas[0].intact() and s.arenas[1].intact()
+    b = batch_of(z, dev)
+    s.alpha_override = torch.from_numpy(z["alpha"])
+    s.G.requires_grad_(False)
+    s.training_step(b, 0, 0).backward()
+    for name, p in s.D.named_parameters():
+        assert relerr(p.grad, torch.from_numpy(z["dgrad." + name])) <= TOL, name
+    s.G.requires_grad_(True)
+    s.D.requires_grad_(False)
+    s2 = build(z, sc["cfg"], dev)
+    s2.optimizers()
+    s2.D.requires_grad_(False)
+    s2.global_step = s2.n_critic - 1
+    s2.training_step(b, 0, 1).backward()
+    for name, p in s2.G.named_parameters():
+        assert relerr(p.grad, torch.from_numpy(z["ggrad." + name])) <= TOL, name
