@@ -65,21 +65,30 @@ class GradSync:
                     v.div_(self.world)
                 grads[i].copy_(v.view_as(grads[i]))
 
-    def allreduce_flat(self, flat: torch.Tensor) -> None:
-        """Average a gradient arena over ranks in place: bucket-sized views of the buffer itself
-        go to the collective, nothing is packed or unpacked."""
+    def allreduce_flat_async(self, flat: torch.Tensor):
+        """Start averaging a gradient arena over ranks in place: bucket-sized views of the buffer
+        itself go to the collective (nothing is packed or unpacked).  Returns a handle for
+        :meth:`finish`; until then the collective runs on the communicator's stream, beside
+        whatever is launched next."""
         if self.world == 1 or flat.numel() == 0:
-            return
+            return []
         backend = dist.get_backend(self.group)
         op = dist.ReduceOp.AVG if backend == "nccl" else dist.ReduceOp.SUM
         work = []
         for off in range(0, flat.numel(), self.bucket_elems):
             v = flat[off:off + self.bucket_elems]
-            work.append((dist.all_reduce(v, op=op, group=self.group, async_op=True), v))
-        for w, v in work:
+            work.append((dist.all_reduce(v, op=op, group=self.group, async_op=True), v, op))
+        return work
+
+    def finish(self, handle) -> None:
+        """Make the current stream wait for the collectives of ``handle``."""
+        for w, v, op in handle:
             w.wait()
             if op == dist.ReduceOp.SUM:
                 v.div_(self.world)
+
+    def allreduce_flat(self, flat: torch.Tensor) -> None:
+        self.finish(self.allreduce_flat_async(flat))
 
     def broadcast_params(self, modules) -> None:
         """Identical initial weights and buffers on all ranks (DDP does this at construction)."""

@@ -116,7 +116,10 @@ class FCDSolver(nn.Module):
         self.loss_dict: Dict[str, torch.Tensor] = {}
         self.alpha_override: Optional[torch.Tensor] = None   # inject alpha (fcd_solver.py:296) for parity tests
         self.grad_sync = None                       # parallel.GradSync when data-parallel
+        self.overlap_comm = True                    # overlap D's gradient all-reduce with the G step's start
+        self._pending = None
         self.build_model()
+        self.D.register_forward_pre_hook(self._flush_pending)
         self.set_precision(getattr(config, "precision", "fp32"))
         self._opts = None
         self.arenas = (None, None)
@@ -243,9 +246,22 @@ class FCDSolver(nn.Module):
             self._opts = (od["optimizer"], og["optimizer"])
         return self._opts
 
+    def _flush_pending(self, *_):
+        """Finish a deferred D update: wait for its gradient all-reduce, Adam step, clear the arena."""
+        if self._pending is None:
+            return
+        handle, opt, step = self._pending
+        self._pending = None
+        self.grad_sync.finish(handle)
+        if step:
+            opt.step()
+        opt.arena.zero_grad()
+
     def _run_optimizer(self, batch, batch_idx, optimizer_idx, step: bool):
         """What Lightning does per optimizer: toggle, closure (training_step + backward), step, zero_grad."""
         opt = self.optimizers()[optimizer_idx]
+        if optimizer_idx == 0:
+            self._flush_pending()
         mine, other = (self.D, self.G) if optimizer_idx == 0 else (self.G, self.D)
         other.requires_grad_(False)
         mine.requires_grad_(True)
@@ -255,6 +271,11 @@ class FCDSolver(nn.Module):
                 loss.backward()
                 arena = opt.arena if opt.arena is not None and opt.arena.intact() else None
                 if self.grad_sync is not None:
+                    if arena is not None and optimizer_idx == 0 and self.overlap_comm:
+                        # D's gradient all-reduce (the large one) runs beside the generator forwards
+                        # that open the G step; D is updated right before it is next used
+                        self._pending = (self.grad_sync.allreduce_flat_async(arena.grad), opt, step)
+                        return loss
                     if arena is not None:
                         self.grad_sync.allreduce_flat(arena.grad)
                     else:
@@ -277,6 +298,7 @@ class FCDSolver(nn.Module):
             self.global_step = self.n_critic - 1 + (self.global_step // self.n_critic) * self.n_critic
         d_loss = self._run_optimizer(batch, batch_idx, 0, True)
         g_loss = self._run_optimizer(batch, batch_idx, 1, (self.global_step + 1) % self.n_critic == 0)
+        self._flush_pending()          # no G update this step: nothing used D in between
         self.global_step += 1
         return d_loss, g_loss
 

@@ -41,6 +41,17 @@ def _worker(rank, world, port, out):
         lin.weight.fill_(float(rank + 1))
     sync.broadcast_params([lin])
     ok = ok and bool((lin.weight == 1.0).all())
+    # arena path: the flat gradient buffer itself is reduced, in bucket-sized views
+    from fcd_amd.arena import ParamArena
+    ps = [torch.nn.Parameter(torch.full(s, float(i))) for i, s in enumerate(shapes)]
+    ar = ParamArena(ps)
+    ok = ok and ar.intact() and all(bool((p == float(i)).all()) for i, p in enumerate(ps))
+    gen = torch.Generator().manual_seed(100 + rank)
+    for p_ in ps:
+        p_.grad.copy_(torch.randn(p_.shape, generator=gen))
+    sync.allreduce_flat(ar.grad)
+    ok = ok and all(torch.allclose(p_.grad, e, atol=1e-6) for p_, e in zip(ps, exp)) and ar.intact()
+    ok = ok and float(ar.grad.abs().sum()) > 0 and ar.flat.numel() % 64 == 0
     out[rank] = ok and not all(torch.equal(a, p.grad) for a, p in zip(local, params))
     dist.destroy_process_group()
 

@@ -223,3 +223,48 @@ def test_arena_gradients_match_fixtures(dev, tiny):
     s2.training_step(b, 0, 1).backward()
     for name, p in s2.G.named_parameters():
         assert relerr(p.grad, torch.from_numpy(z["ggrad." + name])) <= TOL, name
+
+
+class _FakeSync:
+    """Stands in for parallel.GradSync on one GPU: records the calls, reduces nothing."""
+    world = 2
+
+    def __init__(self):
+        self.async_calls = self.sync_calls = self.finished = 0
+
+    def allreduce_flat_async(self, flat):
+        self.async_calls += 1
+        return [("handle", flat)]
+
+    def finish(self, handle):
+        self.finished += len(handle)
+
+    def allreduce_flat(self, flat):
+        self.sync_calls += 1
+
+    def allreduce(self, params):
+        self.sync_calls += 1
+
+
+def test_deferred_d_update_equals_immediate(dev, tiny):
+    """Data-parallel schedule: D's all-reduce is started after its backward and D is updated right
+    before its next use (inside the G step).  Must give bit-identical weights to the immediate
+    update, also on steps that skip the G update."""
+    z, sc = tiny
+    b = batch_of(z, dev)
+    states = []
+    for mode in ("none", "overlap", "sync"):
+        s = build(z, sc["cfg"], dev)
+        s.alpha_override = torch.from_numpy(z["alpha"])
+        if mode != "none":
+            s.grad_sync = _FakeSync()
+            s.overlap_comm = mode == "overlap"
+        for it in range(3):
+            s.train_step(b, force_g=(it != 1))     # middle step: D update only
+        torch.cuda.synchronize()
+        if mode == "overlap":
+            assert s.grad_sync.async_calls == 3 and s.grad_sync.finished == 3 and s._pending is None
+        states.append({k: v.clone() for k, v in list(s.G.state_dict().items()) + list(s.D.state_dict().items())})
+    for other in states[1:]:
+        for k, v in states[0].items():
+            assert torch.equal(v, other[k]), k
