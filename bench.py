@@ -91,6 +91,9 @@ def main():
                          "multi-rank code path on a box with fewer GPUs than ranks")
     args = ap.parse_args()
 
+    if os.environ.get("FCD_HANG_DUMP"):           # debugging aid: stack of every thread after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["FCD_HANG_DUMP"]), exit=True)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -45,10 +45,11 @@ class GradSync:
         work = []
         for bi, idx in enumerate(plan_buckets([g.numel() for g in grads], self.bucket_elems)):
             n = sum(grads[i].numel() for i in idx)
-            key = (bi, n, grads[idx[0]].device)
+            bdev = grads[idx[0]].device if backend == "nccl" else torch.device("cpu")   # gloo reduces host memory
+            key = (bi, n, bdev)
             flat = self._flat.get(key)
             if flat is None:
-                flat = torch.empty(n, dtype=torch.float32, device=grads[idx[0]].device)
+                flat = torch.empty(n, dtype=torch.float32, device=bdev)
                 self._flat[key] = flat
             off = 0
             views = []
@@ -77,15 +78,19 @@ class GradSync:
         work = []
         for off in range(0, flat.numel(), self.bucket_elems):
             v = flat[off:off + self.bucket_elems]
-            work.append((dist.all_reduce(v, op=op, group=self.group, async_op=True), v, op))
+            # gloo (rehearsals on a box with fewer GPUs than ranks) reduces host memory: stage it
+            t = v.cpu() if (backend != "nccl" and v.is_cuda) else v
+            work.append((dist.all_reduce(t, op=op, group=self.group, async_op=True), v, t, op))
         return work
 
     def finish(self, handle) -> None:
         """Make the current stream wait for the collectives of ``handle``."""
-        for w, v, op in handle:
+        for w, v, t, op in handle:
             w.wait()
             if op == dist.ReduceOp.SUM:
-                v.div_(self.world)
+                t.div_(self.world)
+            if t is not v:
+                v.copy_(t)
 
     def allreduce_flat(self, flat: torch.Tensor) -> None:
         self.finish(self.allreduce_flat_async(flat))
@@ -94,6 +99,12 @@ class GradSync:
         """Identical initial weights and buffers on all ranks (DDP does this at construction)."""
         if self.world == 1:
             return
+        staged = dist.get_backend(self.group) != "nccl"
         for m in modules:
             for t in list(m.parameters()) + list(m.buffers()):
-                dist.broadcast(t.data, 0, group=self.group)
+                if staged and t.is_cuda:
+                    h = t.data.cpu()
+                    dist.broadcast(h, 0, group=self.group)
+                    t.data.copy_(h)
+                else:
+                    dist.broadcast(t.data, 0, group=self.group)
