@@ -52,9 +52,14 @@ def dominant_kernel_roofline(precision, dev, iters=20):
     flops = 2.0 * n * 256 * 256 * 9 * h * w
     achieved = flops / (ms * 1e-3) / 1e12
     peak = PEAK_TFLOPS[precision]
-    return {"bound": "mfma", "kernel": "conv_gather_kernel<128,128> 3x3 256->256 @32x32 B16",
+    # HBM-side bytes per launch of this same launch from the rocprofv3 PMC passes committed under
+    # profiles/r1_e_resblock_conv_pmc_*.csv: FETCH_SIZE 17507 KB x 2 (gfx950 correction) + WRITE_SIZE
+    # 16384 KB; algorithmic: 16.8 MB input + 2.4 MB weights + 16.8 MB output.  fp32 launch only.
+    traffic = 2 * 17507 * 1024 + 16384 * 1024 if precision == "fp32" else None
+    return {"bound": "mfma", "kernel": "conv_gather_dma_kernel<128,128> 3x3 256->256 @32x32 B16",
             "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-            "us_per_launch": round(ms * 1e3, 2), "gflop_per_launch": round(flops / 1e9, 3), "traffic": None}
+            "us_per_launch": round(ms * 1e3, 2), "gflop_per_launch": round(flops / 1e9, 3), "traffic": traffic,
+            "traffic_unit": "HBM-side bytes per launch (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; profiles/)"}
 
 
 def cpu_baseline():
