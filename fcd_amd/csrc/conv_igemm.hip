@@ -528,6 +528,20 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
     }
 }
 
+template <int T>
+__device__ __forceinline__ void read_vec(const float* p, float* out) {
+  static_assert(T == 1 || T == 2 || T == 4, "sub-tiles per wave");
+  if constexpr (T == 1) {
+    out[0] = p[0];
+  } else if constexpr (T == 2) {
+    const float2 v = *reinterpret_cast<const float2*>(p);
+    out[0] = v.x; out[1] = v.y;
+  } else {
+    const float4 v = *reinterpret_cast<const float4*>(p);
+    out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+  }
+}
+
 // Weight gradient, fp32, LDS-DMA ring.  LDS tiles are [32 pixels][BM | BN] floats, unpadded (one
 // DMA instruction of a wave writes 1 KiB = 256/BM consecutive pixel rows).
 // M16: at most 16 output channels (v_mfma_f32_16x16x4_f32 tiles; the A stage keeps its 32-column
@@ -680,13 +694,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_dma_kernel(const Wgra
         const int k0 = 16 * s2 + 8 * lh;
 #pragma unroll
         for (int mi = 0; mi < TM; ++mi) {
-          const float* c = As + k0 * BM + wm * WTM + mi * 32 + lr;
+          const float* c = As + k0 * BM + wm * WTM + TM * lr + mi;
           const f32x8 f = {c[0], c[BM], c[2 * BM], c[3 * BM], c[4 * BM], c[5 * BM], c[6 * BM], c[7 * BM]};
           af[mi] = __builtin_convertvector(f, bf16x8_t);
         }
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni) {
-          const float* c = Bs + k0 * BN + wn * WTN + ni * 32 + lr;
+          const float* c = Bs + k0 * BN + wn * WTN + TN * lr + ni;
           const f32x8 f = {c[0], c[BN], c[2 * BN], c[3 * BN], c[4 * BN], c[5 * BN], c[6 * BN], c[7 * BN]};
           bf[ni] = __builtin_convertvector(f, bf16x8_t);
         }
@@ -702,14 +716,14 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_dma_kernel(const Wgra
           }
       }
     } else {
-    // operands of k-step kk+2 are read while the MFMAs of step kk run
+    // operands of k-step kk+2 are read while the MFMAs of step kk run.  The wave's TM (TN)
+    // 32-row sub-tiles are interleaved: lane i of sub-tile e owns row TM*i + e, so that ONE
+    // ds_read_b32/b64/b128 at [pixel][TM*i] feeds all TM sub-tiles.
     float af[3][TM], bf[3][TN];
     auto read_frags = [&](int kk, float* a, float* b) {
       const int kq = 2 * kk + lh;
-#pragma unroll
-      for (int mi = 0; mi < TM; ++mi) a[mi] = As[kq * BM + wm * WTM + mi * 32 + lr];
-#pragma unroll
-      for (int ni = 0; ni < TN; ++ni) b[ni] = Bs[kq * BN + wn * WTN + ni * 32 + lr];
+      read_vec<TM>(As + kq * BM + wm * WTM + TM * lr, a);
+      read_vec<TN>(Bs + kq * BN + wn * WTN + TN * lr, b);
     };
     read_frags(0, af[0], bf[0]);
     read_frags(1, af[1], bf[1]);
@@ -746,16 +760,28 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_dma_kernel(const Wgra
     }
     return;
   }
+  // D[mfma row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)][mfma col = lane&31] of sub-tile (mi, ni) is
+  // output (o = TM*row + mi, column TN*col + ni) of the wave's block; a lane's TN columns are adjacent
 #pragma unroll
   for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < TN; ++ni) {
-      const int col = tn * BN + wn * WTN + ni * 32 + lr;
-      if (col >= p.ND) continue;
+    for (int r = 0; r < 16; ++r) {
+      const int o = tm * BM + wm * WTM + TM * ((r & 3) + 8 * (r >> 2) + 4 * lh) + mi;
+      if (o >= p.O) continue;
+      const int col0 = tn * BN + wn * WTN + TN * lr;
+      float* __restrict__ row = dst + (long)o * p.ND + col0;
+      if (col0 + TN <= p.ND) {
+        if constexpr (TN == 4) {
+          *reinterpret_cast<float4*>(row) = make_float4(acc[mi][0][r], acc[mi][1][r], acc[mi][2][r], acc[mi][3][r]);
+        } else if constexpr (TN == 2) {
+          *reinterpret_cast<float2*>(row) = make_float2(acc[mi][0][r], acc[mi][1][r]);
+        } else {
+          row[0] = acc[mi][0][r];
+        }
+      } else {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int o = tm * BM + wm * WTM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (o < p.O) dst[(long)o * p.ND + col] = acc[mi][ni][r];
+        for (int ni = 0; ni < TN; ++ni)
+          if (col0 + ni < p.ND) row[ni] = acc[mi][ni][r];
       }
     }
 }
@@ -946,7 +972,7 @@ extern "C" int fcd_conv_gather(const FcdConvDesc* d, const float* in, const floa
   return rc;
 }
 
-static int wgrad_bm(const FcdWgradDesc* d) { return d->O <= 32 ? 32 : (d->O <= 64 ? 64 : 128); }
+static int wgrad_bm(const FcdWgradDesc* d) { return d->O <= 32 ? 32 : (d->O <= 64 ? 64 : (d->O <= 128 ? 128 : 256)); }
 
 static int resolve_wgrad_splitk(const FcdWgradDesc* d) {
   if (d->splitk > 0) return d->splitk;
@@ -954,7 +980,9 @@ static int resolve_wgrad_splitk(const FcdWgradDesc* d) {
   const int ktiles = fcd_cdiv((long)d->N * d->GH * d->GW, 32);
   // aim at one workgroup per CU (the DMA ring keeps a lone workgroup's MFMA pipes fed); more
   // splits only add slab traffic
-  long sk = (256 + tiles / 2) / tiles;
+  // (the 16-row kernel is short of MFMA work per tile: two workgroups per CU hide its DMA latency)
+  const long want = (d->O <= 16 && d->precision == FCD_PREC_F32) ? 512 : 256;
+  long sk = (want + tiles / 2) / tiles;
   if (sk > ktiles / 8) sk = ktiles / 8;
   if (sk > 512) sk = 512;
   if (sk < 1) sk = 1;
@@ -1014,9 +1042,12 @@ extern "C" int fcd_conv_wgrad(const FcdWgradDesc* d, const float* gsmall, const 
   } else if (d->O <= 64) {
     a.tiles_m = fcd_cdiv(d->O, 64); a.tiles_n = fcd_cdiv(a.ND, 128);
     rc = launch_wgrad<64, 128, 2, 4>(a, d->precision, st);
-  } else {
+  } else if (d->O <= 128) {
     a.tiles_m = fcd_cdiv(d->O, 128); a.tiles_n = fcd_cdiv(a.ND, 128);
     rc = launch_wgrad<128, 128, 2, 4>(a, d->precision, st);
+  } else {
+    a.tiles_m = fcd_cdiv(d->O, 256); a.tiles_n = fcd_cdiv(a.ND, 128);
+    rc = launch_wgrad<256, 128, 4, 2>(a, d->precision, st);
   }
   if (rc) return rc;
   const int blocks = d->O * fcd_cdiv(d->I, WR_IC);
