@@ -90,6 +90,11 @@ PROTOTYPES = {
     "fcd_gp_bwd": (_I, [_P, _P, _P, _P, _I, _Z, _P]),
     "fcd_adam_step": (_I, [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _I, _P]),
     "fcd_diffmap_threshold": (_I, [_P, _P, _P, _P, _F, _I, _I, _I, _I, _P]),
+    "fcd_scene_tiles": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _P, _P]),
+    "fcd_scene_stitch": (_I, [_P, _P, _I, _I, _P, _I, _I, _P]),
+    "fcd_scene_binarize": (_I, [_P, _P, _I, _I, _I, C.c_double, _P, _P]),
+    "fcd_valid_minmax": (_I, [_P, _P, C.c_size_t, _P, _P]),
+    "fcd_threshold_hist": (_I, [_P, _P, C.c_size_t, _P, _I, _P, _P]),
 }
 
 _lib: Optional[C.CDLL] = None
@@ -150,10 +155,10 @@ class _Workspace:
 workspace = _Workspace()
 
 
-def require_gpu_tensor(t: torch.Tensor, name: str) -> None:
+def require_gpu_tensor(t: torch.Tensor, name: str, dtype: torch.dtype = torch.float32) -> None:
     if not t.is_cuda:
         raise RuntimeError(f"fcd_amd: {name} must live on the GPU (got {t.device}); the HIP path has no CPU fallback")
-    if t.dtype != torch.float32:
-        raise RuntimeError(f"fcd_amd: {name} must be float32 (got {t.dtype})")
+    if t.dtype != dtype:
+        raise RuntimeError(f"fcd_amd: {name} must be {dtype} (got {t.dtype})")
     if not t.is_contiguous():
         raise RuntimeError(f"fcd_amd: {name} must be contiguous")

@@ -403,3 +403,68 @@ def diffmap_threshold(x_fake, x, thr: Optional[float], want_diff: bool = True):
     check(L.load().fcd_diffmap_threshold(ptr(x_fake), ptr(x), ptr(diff), ptr(mask), 0.0 if thr is None else float(thr),
                                          n, c, h, w, stream()), "diffmap_threshold")
     return diff, mask
+
+
+# --------------------------------------------------------------------------- #
+# scene path / threshold search on the device
+# --------------------------------------------------------------------------- #
+def scene_tiles(scene: torch.Tensor, origins: torch.Tensor, patch: int):
+    """scene (H, W, C) uint16 and origins (nb, 2) int32 on the device -> x (nb, C, patch, patch)
+    fp32 in [-1, 1] and a device int that is 1 if any sample of the batch is non-zero."""
+    if scene.dtype != torch.uint16 or origins.dtype != torch.int32:
+        raise TypeError("scene_tiles: scene must be uint16 and origins int32")
+    L.require_gpu_tensor(scene, "scene", torch.uint16)
+    L.require_gpu_tensor(origins, "origins", torch.int32)
+    h, w, c = scene.shape
+    nb = origins.shape[0]
+    x = torch.empty((nb, c, patch, patch), dtype=torch.float32, device=scene.device)
+    flag = torch.zeros((), dtype=torch.int32, device=scene.device)
+    check(L.load().fcd_scene_tiles(ptr(scene), h, w, c, patch, ptr(origins), nb, ptr(x), ptr(flag), stream()), "scene_tiles")
+    return x, flag
+
+
+def scene_stitch(delta: torch.Tensor, origins: torch.Tensor, raster: torch.Tensor) -> None:
+    nb, patch, _ = delta.shape
+    h, w = raster.shape
+    if raster.dtype != torch.float64 or delta.dtype != torch.float32:
+        raise TypeError("scene_stitch: delta fp32, raster float64")
+    L.require_gpu_tensor(delta, "delta")
+    L.require_gpu_tensor(raster, "raster", torch.float64)
+    L.require_gpu_tensor(origins, "origins", torch.int32)
+    check(L.load().fcd_scene_stitch(ptr(delta), ptr(origins), nb, patch, ptr(raster), h, w, stream()), "scene_stitch")
+
+
+def scene_binarize(raster: torch.Tensor, scene: torch.Tensor, threshold: float) -> torch.Tensor:
+    h, w, c = scene.shape
+    if tuple(raster.shape) != (h, w) or raster.dtype != torch.float64:
+        raise RuntimeError("scene_binarize: raster must be (H, W) float64")
+    L.require_gpu_tensor(raster, "raster", torch.float64)
+    L.require_gpu_tensor(scene, "scene", torch.uint16)
+    mask = torch.empty((h, w), dtype=torch.uint8, device=raster.device)
+    check(L.load().fcd_scene_binarize(ptr(raster), ptr(scene), h, w, c, float(threshold), ptr(mask), stream()),
+          "scene_binarize")
+    return mask
+
+
+def valid_minmax(diff: torch.Tensor, target: torch.Tensor, minmax: torch.Tensor) -> None:
+    """Fold min / max of ``diff`` where ``target > 0`` into ``minmax`` (2 fp32, start at [inf, 0])."""
+    if diff.numel() != target.numel() or target.dtype != torch.uint8 or diff.dtype != torch.float32:
+        raise RuntimeError("valid_minmax: diff fp32 and target uint8 of the same size")
+    L.require_gpu_tensor(diff, "diff")
+    L.require_gpu_tensor(target, "target", torch.uint8)
+    L.require_gpu_tensor(minmax, "minmax")
+    check(L.load().fcd_valid_minmax(ptr(diff), ptr(target), diff.numel(), ptr(minmax), stream()), "valid_minmax")
+
+
+def threshold_hist(diff: torch.Tensor, target: torch.Tensor, thresholds: torch.Tensor, hist: torch.Tensor) -> None:
+    """Add this batch to ``hist`` (2, T+1) int64: see ``fcd_threshold_hist`` in include/fcd_hip.h."""
+    t = thresholds.numel()
+    if hist.dtype != torch.int64 or tuple(hist.shape) != (2, t + 1) or thresholds.dtype != torch.float32:
+        raise RuntimeError("threshold_hist: hist must be (2, T+1) int64 and thresholds fp32")
+    if diff.numel() != target.numel() or target.dtype != torch.uint8 or diff.dtype != torch.float32:
+        raise RuntimeError("threshold_hist: diff fp32 and target uint8 of the same size")
+    L.require_gpu_tensor(diff, "diff")
+    L.require_gpu_tensor(target, "target", torch.uint8)
+    L.require_gpu_tensor(hist, "hist", torch.int64)
+    check(L.load().fcd_threshold_hist(ptr(diff), ptr(target), diff.numel(), ptr(thresholds), t, ptr(hist), stream()),
+          "threshold_hist")

@@ -4,8 +4,12 @@ Mirrors ``evaluate.predict_scene`` (``evaluate.py:84-123``) with ``PatchDataset`
 (``data_loader.py:74-103``, crop_size 0): reflect-pad to a multiple of the patch, row-major
 patches, skip batches that are entirely nodata (all == -1), ``G(x, 0)``, ``|x_fake - x| / 2``,
 band mean, ``+=`` into a float64 raster, then ``binarize`` (numpy ``>`` in float64).
-G, the difference map and the band mean run on the GPU (HIP); tiling and stitching are host numpy
-like the reference (SURVEY 8(f) rank 1 moves them to the device later).
+``predict_scene`` keeps everything on the device: the uint16 scene is uploaded once, a kernel cuts
+and normalises each batch of patches (reflect padding by index arithmetic, no padded copy), G and the
+difference map run as in training, a kernel adds the tiles into a float64 raster, and
+``generate_scene_mask`` zeroes nodata and compares in float64 on the device.
+``predict_scene_host`` is the same computation with the reference's host-side numpy tiling and
+stitching (used by the tests to pin the device path bit for bit).
 """
 from __future__ import annotations
 
@@ -23,10 +27,37 @@ def scene_patches(h: int, w: int, patch: int, crop: int = 0):
     return origins, pad_h, pad_w, cps
 
 
+def _device_scene(full_image: np.ndarray, solver, patch: int, batch_size: int):
+    """-> (scene on the device, float64 raster on the device)."""
+    from . import ops
+    if full_image.dtype != np.uint16:
+        raise TypeError("predict_scene expects a uint16 scene (data_loader.py:76)")
+    h, w, _ = full_image.shape
+    origins, _, _, _ = scene_patches(h, w, patch, 0)
+    dev = solver.device
+    scene = torch.from_numpy(np.ascontiguousarray(full_image)).to(dev)
+    org = torch.tensor(origins, dtype=torch.int32, device=dev).view(-1, 2)
+    raster = torch.zeros((h, w), dtype=torch.float64, device=dev)
+    for s in range(0, len(origins), batch_size):
+        o = org[s:s + batch_size].contiguous()
+        x, any_valid = ops.scene_tiles(scene, o, patch)
+        if int(any_valid.item()) == 0:     # don't waste time on invalid patches (evaluate.py:104)
+            continue
+        ops.scene_stitch(solver.compute_difference_map(x), o, raster)
+    return scene, raster
+
+
 @torch.no_grad()
 def predict_scene(full_image: np.ndarray, solver, patch_size: int = None, batch_size: int = 64) -> np.ndarray:
-    """(H, W, bands) uint16 -> (H, W) float64 difference raster.  Uses ``solver.G`` in its current
-    train/eval mode, exactly like the reference."""
+    """(H, W, bands) uint16 -> (H, W) float64 difference raster (``evaluate.py:84-123``).  Uses
+    ``solver.G`` in its current train/eval mode, exactly like the reference."""
+    _, raster = _device_scene(full_image, solver, patch_size or solver.image_size, batch_size)
+    return raster.cpu().numpy()
+
+
+@torch.no_grad()
+def predict_scene_host(full_image: np.ndarray, solver, patch_size: int = None, batch_size: int = 64) -> np.ndarray:
+    """``predict_scene`` with the reference's host-side tiling and stitching."""
     if full_image.dtype != np.uint16:
         raise TypeError("predict_scene expects a uint16 scene (data_loader.py:76)")
     patch = patch_size or solver.image_size
@@ -50,7 +81,8 @@ def predict_scene(full_image: np.ndarray, solver, patch_size: int = None, batch_
 
 def generate_scene_mask(full_image: np.ndarray, solver, threshold: float = 0.02, batch_size: int = 64):
     """difference raster -> nodata zeroed -> ``solver.binarize`` (``evaluate.py:49-51``)."""
-    diff = predict_scene(full_image, solver, batch_size=batch_size)
-    valid = np.any(full_image != 0, axis=2)
-    diff[~valid] = 0
-    return diff, solver.binarize(diff, threshold)
+    from . import ops
+    with torch.no_grad():
+        scene, raster = _device_scene(full_image, solver, solver.image_size, batch_size)
+        mask = ops.scene_binarize(raster, scene, threshold)
+    return raster.cpu().numpy(), mask.cpu().numpy()

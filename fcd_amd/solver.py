@@ -37,6 +37,35 @@ def default_config(**over) -> Namespace:
     return Namespace(**cfg)
 
 
+def f1_score(cm: np.ndarray) -> float:
+    """Macro F1 of a confusion matrix ``cm[truth][prediction]`` (``metrics.py:33-45``)."""
+    f1s = []
+    for i in range(cm.shape[0]):
+        tp = int(cm[i, i])
+        fp = int(cm[:, i].sum()) - tp
+        fn = int(cm[i, :].sum()) - tp
+        denom = 2 * tp + fp + fn
+        f1s.append(1 if denom == 0 else 2 * float(tp) / denom)
+    return float(np.mean(f1s))
+
+
+def best_threshold_from_hist(hist: np.ndarray, thresholds: np.ndarray) -> float:
+    """The reference's sweep (``fcd_solver.py:713-721``: keep going while F1 does not drop) on the
+    device histogram: ``hist[cls][j]`` = valid pixels of class ``cls`` predicted 1 for exactly the
+    first ``j`` thresholds."""
+    total = hist.sum(axis=1)
+    best_f1, best_thr = None, None
+    for t, thr in enumerate(thresholds):
+        pred1 = hist[:, t + 1:].sum(axis=1)
+        cm = np.array([[total[0] - pred1[0], pred1[0]], [total[1] - pred1[1], pred1[1]]], dtype=np.int64)
+        f1 = f1_score(cm)
+        if best_f1 is None or f1 >= best_f1:
+            best_f1, best_thr = f1, float(thr)
+        else:
+            break
+    return best_thr
+
+
 class FusedAdam(torch.optim.Optimizer):
     """torch.optim.Adam(lr, betas) semantics (``fcd_solver.py:183,186``) with the HIP update.
 
@@ -345,32 +374,33 @@ class FCDSolver(nn.Module):
 
     @torch.no_grad()
     def find_best_threshold(self, n_thresholds=30, dataset: Optional[Iterable] = None):
-        """Threshold sweep maximising macro F1 on samples with ground-truth masks
-        (``fcd_solver.py:680-725``, first local maximum like the reference's early ``break``)."""
+        """Threshold sweep maximising macro F1 on samples ``{'image', 'mask'}`` with ground-truth
+        masks (0 invalid, 1 clear, 2 cloudy): ``fcd_solver.py:680-725`` with ``metrics.py``'s
+        confusion matrix / F1, first local maximum like the reference's early ``break``.
+        Difference maps stay on the device; min/max and the per-threshold confusion counts are two
+        device passes (``fcd_valid_minmax``, ``fcd_threshold_hist``).  The comparison
+        ``preds > threshold`` is done in fp32 with the threshold rounded to fp32, as numpy 1.x
+        (the reference's era) does for a float32 array against a float64 scalar."""
         self.G.eval()
-        preds, targets = [], []
+        dev = self.device
+        diffs, targets = [], []
+        minmax = torch.tensor([float("inf"), 0.0], dtype=torch.float32, device=dev)
         for sample in dataset:
-            d = self.compute_difference_map(sample["image"].to(self.device)).cpu().numpy().astype(np.float32)
-            t = sample["mask"].numpy()
-            valid = t > 0
-            preds.append(d[valid])
-            targets.append(t[valid] - 1)
-        preds, targets = np.concatenate(preds), np.concatenate(targets)
-        best_f1, best_thr = None, None
-        for thr in np.linspace(preds.min(), preds.max(), n_thresholds):
-            p = (preds > thr).astype(np.uint8)
-            f1s = []
-            for cls in (0, 1):
-                tp = float(np.sum((p == cls) & (targets == cls)))
-                fp = float(np.sum((p == cls) & (targets != cls)))
-                fn = float(np.sum((p != cls) & (targets == cls)))
-                f1s.append(2 * tp / max(2 * tp + fp + fn, 1e-12))
-            f1 = float(np.mean(f1s))
-            if best_f1 is None or f1 >= best_f1:
-                best_f1, best_thr = f1, float(thr)
-            else:
-                break
-        return best_thr, dataset
+            d = self.compute_difference_map(sample["image"].to(dev))
+            t = sample["mask"].to(dev).to(torch.uint8).contiguous()
+            ops.valid_minmax(d, t, minmax)
+            diffs.append(d)
+            targets.append(t)
+        lo, hi = (float(v) for v in minmax.cpu())
+        if not diffs or lo == float("inf"):
+            raise ValueError("find_best_threshold: no valid pixels")
+        thresholds = np.linspace(start=np.float32(lo), stop=np.float32(hi), num=n_thresholds)
+        thr32 = torch.from_numpy(thresholds.astype(np.float32)).to(dev)
+        hist = torch.zeros((2, n_thresholds + 1), dtype=torch.int64, device=dev)
+        for d, t in zip(diffs, targets):
+            ops.threshold_hist(d, t, thr32, hist)
+        best = best_threshold_from_hist(hist.cpu().numpy(), thresholds)
+        return best, dataset
 
     def binarize(self, difference, threshold=0.2):
         """numpy ``>`` in the array's own dtype (``fcd_solver.py:566-567``)."""

@@ -223,6 +223,42 @@ int fcd_adam_step(float* p, const float* g, float* m, float* v, size_t n, float 
 int fcd_diffmap_threshold(const float* x_fake, const float* x, float* diff, uint8_t* mask,
                           float thr, int N, int C, int H, int W, void* stream);
 
+/* ------------------------------------------------------------------------- *
+ * Scene path on the device.
+ *
+ * fcd_scene_tiles: PatchDataset.__getitem__ + Normalize for a batch of patches
+ *   (data_loader.py:74-103 with crop_size 0, evaluate.py:90-93): scene[H][W][C] uint16,
+ *   origins_rc[nb][2] = (row, col) patch origins (device memory), numpy 'reflect' padding
+ *   past the bottom/right edge, x = (v - 32767.5) * fp32(1/32767.5) written NCHW fp32.
+ *   *any_valid (device int, zeroed by the caller) is set to 1 if any sample is non-zero:
+ *   the caller skips all-nodata batches like evaluate.py:104.
+ * fcd_scene_stitch: difference[row:row+h, col:col+w] += delta[b, :h, :w] in float64
+ *   (evaluate.py:117-122); delta[nb][patch][patch] fp32, raster[H][W] double.
+ * fcd_scene_binarize: difference[~valid] = 0 with valid = any band != 0, then
+ *   mask = difference > threshold compared in float64 (evaluate.py:49-51,
+ *   fcd_solver.py:566-567); raster is updated in place, mask[H][W] uint8.
+ * ------------------------------------------------------------------------- */
+int fcd_scene_tiles(const uint16_t* scene, int H, int W, int C, int patch, const int* origins_rc, int nb,
+                    float* x_nchw, int* any_valid, void* stream);
+int fcd_scene_stitch(const float* delta, const int* origins_rc, int nb, int patch, double* raster, int H,
+                     int W, void* stream);
+int fcd_scene_binarize(double* raster, const uint16_t* scene, int H, int W, int C, double threshold,
+                       uint8_t* mask, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Threshold search (fcd_solver.py:680-725, metrics.py:4-15).
+ * target: 0 = invalid, 1 = clear, 2 = cloudy (class = target - 1).
+ * fcd_valid_minmax folds min / max of diff over valid pixels into minmax[2]
+ *   (device floats, initialised by the caller to +inf and 0; diff >= 0).
+ * fcd_threshold_hist adds to hist[2][T+1] (device uint64, zeroed by the caller):
+ *   hist[cls][j] counts valid pixels of class cls whose diff exceeds exactly the first j of
+ *   the ascending fp32 thresholds, i.e. that are predicted 1 for thresholds 0..j-1; the
+ *   confusion matrix of threshold t follows by suffix sums.  Integer counts: exact.
+ * ------------------------------------------------------------------------- */
+int fcd_valid_minmax(const float* diff, const uint8_t* target, size_t n, float* minmax, void* stream);
+int fcd_threshold_hist(const float* diff, const uint8_t* target, size_t n, const float* thresholds, int T,
+                       unsigned long long* hist, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -309,6 +309,41 @@ def binarize(diff: np.ndarray, thr: float = 0.2) -> np.ndarray:
     return (diff > thr).astype(np.uint8)
 
 
+def compute_confusion_matrix(prediction: np.ndarray, ground_truth: np.ndarray, num_classes: int) -> np.ndarray:
+    """``metrics.py:4-15``: ``cm[truth][prediction]`` counts."""
+    idx = ground_truth.astype(np.int64).ravel() * num_classes + prediction.astype(np.int64).ravel()
+    return np.bincount(idx, minlength=num_classes * num_classes).reshape(num_classes, num_classes)
+
+
+def f1_score(cm: np.ndarray) -> float:
+    """``metrics.py:33-45`` (macro F1; an empty class scores 1)."""
+    f1s = []
+    for i in range(cm.shape[0]):
+        tp = int(cm[i, i])
+        fp = int(cm[:, i].sum()) - tp
+        fn = int(cm[i, :].sum()) - tp
+        denom = 2 * tp + fp + fn
+        f1s.append(1 if denom == 0 else 2 * float(tp) / denom)
+    return float(np.mean(f1s))
+
+
+def find_best_threshold(all_preds: np.ndarray, all_targets: np.ndarray, n_thresholds: int = 30) -> float:
+    """``fcd_solver.py:708-721`` on already gathered valid pixels (``all_preds`` fp32 difference
+    values, ``all_targets`` in {0, 1}).  ``all_preds > threshold`` is evaluated in fp32 with the
+    threshold rounded to fp32: numpy 1.x (value-based casting, the reference's era) does that for a
+    float32 array against a float64 scalar; numpy 2 would compare in float64."""
+    thresholds = np.linspace(start=all_preds.min(), stop=all_preds.max(), num=n_thresholds)
+    best_f1, best_threshold = None, None
+    for threshold in thresholds:
+        preds = (all_preds > np.float32(threshold)).astype(np.uint8)
+        f1 = f1_score(compute_confusion_matrix(preds, all_targets, 2))
+        if best_f1 is None or f1 >= best_f1:
+            best_f1, best_threshold = f1, float(threshold)
+        else:
+            break
+    return best_threshold
+
+
 def normalize_u16(v: np.ndarray) -> np.ndarray:
     """uint16 -> [-1, 1] fp32: ``(v / 65535 - 0.5) / 0.5`` (``data_loader.py:375``,
     albumentations Normalize(mean .5, std .5, max 65535)): fp32 arithmetic as

@@ -48,3 +48,102 @@ def test_pseudo_masks_encoding(dev):
     far = (d - 0.02794).abs().numpy() > 1e-5
     assert np.array_equal(m[far], ref[far])
     assert s.generate_masks.__func__ is s.make_psuedo_masks.__func__
+
+
+def _scene(h, w, seed=5):
+    rng = np.random.default_rng(seed)
+    sc = rng.integers(1, 65536, size=(h, w, 10), dtype=np.uint16)
+    sc[:9] = 0                       # nodata border (all bands zero)
+    sc[:, -7:] = 0
+    sc[40:80, 0:40] = 0              # one patch that is entirely nodata
+    return sc
+
+
+@pytest.mark.parametrize("hw", [(100, 77), (96, 64), (33, 130)])
+def test_device_scene_path_equals_host_path(dev, hw):
+    """Tiling (reflect padding, ragged and exact multiples of the patch), normalisation, the
+    all-nodata batch skip and the float64 stitch on the device are bit-identical to the
+    reference's host-side numpy tiling around the same G."""
+    from fcd_amd.scene import generate_scene_mask, predict_scene, predict_scene_host
+    s = tiny_solver(dev)
+    s.G.eval()
+    sc = _scene(*hw)
+    for bs in (1, 3):
+        a = predict_scene(sc, s, batch_size=bs)
+        b = predict_scene_host(sc, s, batch_size=bs)
+        assert a.dtype == np.float64 and np.array_equal(a, b)
+    # nodata zeroing + float64 compare on the device == numpy on the host raster
+    d, m = generate_scene_mask(sc, s, 0.02, batch_size=3)
+    ref = predict_scene_host(sc, s, batch_size=3)
+    ref[~np.any(sc != 0, axis=2)] = 0
+    assert np.array_equal(d, ref) and np.array_equal(m, (ref > 0.02).astype(np.uint8))
+    # a threshold that equals a raster value exactly: strict '>' in float64
+    thr = float(ref[ref > 0].flat[0])
+    _, m2 = generate_scene_mask(sc, s, thr, batch_size=3)
+    assert np.array_equal(m2, (ref > thr).astype(np.uint8))
+
+
+def test_scene_tiles_kernel_against_numpy(dev):
+    """fcd_scene_tiles alone: numpy.pad(..., 'reflect') + slicing + normalisation, bit-exact."""
+    from fcd_amd import ops
+    from fcd_amd.scene import scene_patches
+    sc = _scene(70, 45, seed=9)
+    patch = 32
+    origins, pad_h, pad_w, _ = scene_patches(70, 45, patch, 0)
+    padded = np.pad(sc, (pad_h, pad_w, (0, 0)), "reflect")
+    ref = np.stack([O.normalize_u16(padded[r:r + patch, c:c + patch]) for r, c in origins]).transpose(0, 3, 1, 2)
+    x, flag = ops.scene_tiles(torch.from_numpy(sc).to(dev), torch.tensor(origins, dtype=torch.int32, device=dev), patch)
+    assert int(flag.item()) == 1 and np.array_equal(x.cpu().numpy(), ref)
+    z = np.zeros((40, 40, 10), dtype=np.uint16)
+    x, flag = ops.scene_tiles(torch.from_numpy(z).to(dev), torch.tensor([[0, 0]], dtype=torch.int32, device=dev), patch)
+    assert int(flag.item()) == 0 and bool((x == -1).all())
+    with pytest.raises(RuntimeError):       # scene smaller than a patch: multi-reflection is not supported
+        ops.scene_tiles(torch.from_numpy(z[:20]).to(dev), torch.tensor([[0, 0]], dtype=torch.int32, device=dev), patch)
+
+
+def test_find_best_threshold_on_device(dev):
+    """Device min/max + confusion histogram reproduce the oracle's numpy sweep exactly
+    (integer counts, same fp32 comparison), incl. invalid pixels and ties at the thresholds."""
+    from fcd_amd import ops
+    from fcd_amd.solver import best_threshold_from_hist
+    s = tiny_solver(dev)
+    batch, _ = O.synth_batch(6, 32, 10)
+    x = batch[0]
+    rng = np.random.default_rng(3)
+    samples = []
+    for i in range(0, 6, 2):
+        d = O.difference_map(O.synth_generator_state(8, 1, 2, 10), x[i:i + 2], False).numpy()
+        tgt = (d > np.median(d)).astype(np.uint8) + 1            # cloudy where the map is high ...
+        flip = rng.random(tgt.shape) < 0.2
+        tgt[flip] = 3 - tgt[flip]                                # ... with label noise
+        tgt[x[i:i + 2, 0].numpy() == -1] = 0                     # nodata is invalid
+        samples.append({"image": x[i:i + 2], "mask": torch.from_numpy(tgt)})
+    thr, _ = s.find_best_threshold(n_thresholds=30, dataset=samples)
+    # oracle on the HIP path's own difference maps (the sweep is what is under test here)
+    s.G.eval()
+    preds, tgts = [], []
+    for smp in samples:
+        d = s.compute_difference_map(smp["image"].to(dev)).cpu().numpy()
+        t = smp["mask"].numpy()
+        preds.append(d[t > 0])
+        tgts.append(t[t > 0] - 1)
+    preds, tgts = np.concatenate(preds), np.concatenate(tgts)
+    assert thr == O.find_best_threshold(preds, tgts, 30)
+    # the histogram itself, against numpy counts for every threshold (no early break)
+    thresholds = np.linspace(preds.min(), preds.max(), 30)
+    thresholds[7] = preds[11]                                    # a threshold that ties with a value
+    thresholds = np.sort(thresholds)
+    hist = torch.zeros((2, 31), dtype=torch.int64, device=dev)
+    dd = torch.from_numpy(np.concatenate([p for p in preds.reshape(1, -1)])).to(dev)
+    tt = torch.from_numpy((tgts + 1).astype(np.uint8)).to(dev)
+    ops.threshold_hist(dd, tt, torch.from_numpy(thresholds.astype(np.float32)).to(dev), hist)
+    h = hist.cpu().numpy()
+    for t, th in enumerate(thresholds):
+        p = preds > np.float32(th)
+        for cls in (0, 1):
+            assert h[cls, t + 1:].sum() == int(np.sum(p & (tgts == cls))), (t, cls)
+    assert h.sum() == preds.size
+    mm = torch.tensor([float("inf"), 0.0], device=dev)
+    ops.valid_minmax(dd, tt, mm)
+    assert float(mm[0]) == float(preds.min()) and float(mm[1]) == float(preds.max())
+    assert best_threshold_from_hist(h, thresholds) is not None
