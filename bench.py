@@ -27,9 +27,17 @@ GFLOP_PER_IMG = 293.72
 PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0}   # MI355X_MICROARCH.md dense MFMA peaks
 
 
-def dominant_kernel_roofline(precision, dev, iters=20):
+def is_dominant(d):
+    """The hottest launch: 3x3 s1 256->256 conv at 32x32, B=16 (residual blocks, forward and dgrad)."""
+    return (d.Cin == 256 and d.Cout == 256 and d.KH == 3 and d.KW == 3 and d.IH == 32 and d.IW == 32
+            and d.N == BASE["batch"] and d.nphase == 1)
+
+
+def dominant_kernel_roofline(precision, dev, in_step_us=None, in_step_launches=0, iters=20):
     """The hottest kernel: 3x3 s1 256->256 conv at 32x32, B=16 (forward form; dgrad runs the
-    same kernel with flipped taps).  FLOPs per launch = 2*B*Cin*Cout*9*H*W."""
+    same kernel with flipped taps).  FLOPs per launch = 2*B*Cin*Cout*9*H*W.  `achieved` uses the
+    average duration of this launch inside the timed training steps (HIP events around each of its
+    launches on the launch stream); the back-to-back loop below is reported beside it."""
     from fcd_amd import _lib as L, ops
     g = ops.ConvGeom(256, 256, 3, 1, 1)
     n, h, w = BASE["batch"], 32, 32
@@ -48,7 +56,8 @@ def dominant_kernel_roofline(precision, dev, iters=20):
         ops.conv_gather(d, x, wf, out=out)
     e1.record()
     torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / iters
+    loop_us = e0.elapsed_time(e1) / iters * 1e3
+    ms = (in_step_us if in_step_us else loop_us) * 1e-3
     flops = 2.0 * n * 256 * 256 * 9 * h * w
     achieved = flops / (ms * 1e-3) / 1e12
     peak = PEAK_TFLOPS[precision]
@@ -58,8 +67,56 @@ def dominant_kernel_roofline(precision, dev, iters=20):
     traffic = 2 * 17507 * 1024 + 16384 * 1024 if precision == "fp32" else None
     return {"bound": "mfma", "kernel": "conv_gather_dma_kernel<128,128> 3x3 256->256 @32x32 B16",
             "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-            "us_per_launch": round(ms * 1e3, 2), "gflop_per_launch": round(flops / 1e9, 3), "traffic": traffic,
+            "us_per_launch": round(ms * 1e3, 2), "launches_timed": in_step_launches,
+            "timed": "HIP events around every launch of this kernel in 2 training steps run right after the timed "
+                     "region (an event pair per launch slows the step ~14 %, so they stay out of `value`)" if in_step_us
+            else "back-to-back loop", "us_per_launch_back_to_back_loop": round(loop_us, 2),
+            "gflop_per_launch": round(flops / 1e9, 3), "traffic": traffic,
             "traffic_unit": "HBM-side bytes per launch (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; profiles/)"}
+
+
+def hbm_kernel_roofline(dev, iters=20):
+    """The largest bandwidth-bound kernel pair: InstanceNorm apply (+ReLU) on the (16,128,128,64)
+    activation: 1 read + 1 write = 2 x 67.1 MB algorithmic bytes per launch."""
+    from fcd_amd import ops
+    n, h, w, c = BASE["batch"], 128, 128, 64
+    z = torch.randn(n, h, w, c, device=dev)
+    mean, rstd, _ = ops.instnorm_stats(z)
+    gamma, beta = torch.ones(c, device=dev), torch.zeros(c, device=dev)
+    out = ops.instnorm_apply(z, mean, rstd, gamma, beta, 0.0)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        ops.instnorm_apply(z, mean, rstd, gamma, beta, 0.0, out=out)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    nbytes = 2.0 * z.numel() * 4
+    return {"bound": "hbm", "kernel": "in_apply_kernel (16,128,128,64) fp32", "achieved": round(nbytes / (ms * 1e-3) / 1e9, 1),
+            "peak": 8000.0, "unit": "GB/s", "frac": round(nbytes / (ms * 1e-3) / 8e12, 4),
+            "us_per_launch": round(ms * 1e3, 2), "mbytes_per_launch": round(nbytes / 1e6, 1)}
+
+
+def inference_rate(solver, dev, iters=5):
+    """BASELINE.json configs[3]-style inference: G in eval mode + difference map + threshold at
+    B=64 (generate_masks' inner loop), inputs resident in HBM."""
+    from fcd_amd.synth import synth_batch
+    batch, _ = synth_batch(64, BASE["size"], BASE["bands"], seed=7)
+    x = batch[0].to(dev)
+    was_training = solver.G.training
+    solver.G.eval()
+    with torch.no_grad():
+        solver.difference_and_mask(x, 0.027)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            solver.difference_and_mask(x, 0.027)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    solver.G.train(was_training)
+    return {"metric": "generate_masks images/sec (G eval + difference map + threshold, B=64)",
+            "value": round(64 * iters / dt, 1), "unit": "images/sec", "ms_per_batch": round(dt / iters * 1e3, 2)}
 
 
 def cpu_baseline():
@@ -135,6 +192,7 @@ def main():
     def step():
         solver.train_step(batch, force_g=True)
 
+    from fcd_amd import ops
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -147,6 +205,16 @@ def main():
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
+    # The dominant kernel's duration inside real training steps: HIP events around each of its
+    # launches in two more steps of the same loop.  Kept out of the timed region above because an
+    # event pair per launch (108 per step) costs the step ~14 %.
+    timer = ops.KernelTimer(is_dominant)
+    if world == 1:
+        ops.KERNEL_TIMER = timer
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        ops.KERNEL_TIMER = None
     if dist is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -165,7 +233,10 @@ def main():
                           "global_batch": BASE["batch"] * world, "parallelism": f"dp{world}",
                           "precision": args.precision},
                "step_tflops": round(GFLOP_PER_IMG * BASE["batch"] / (ms * 1e-3) / 1e3, 2)}
-        res["roofline"] = dominant_kernel_roofline(args.precision, dev)
+        res["roofline"] = dominant_kernel_roofline(args.precision, dev, timer.mean_us() if timer.pairs else None,
+                                                   len(timer.pairs))
+        res["roofline_hbm"] = hbm_kernel_roofline(dev)
+        res["inference"] = inference_rate(solver, dev)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)

@@ -122,6 +122,22 @@ class ConvGeom:
         return self.k if self.s == 1 else 2
 
 
+class KernelTimer:
+    """HIP-event timing of selected conv_gather launches on the launch stream (bench.py uses it to
+    time the dominant kernel inside the real training steps)."""
+
+    def __init__(self, match):
+        self.match = match
+        self.pairs = []
+
+    def mean_us(self) -> float:
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in self.pairs) / max(1, len(self.pairs)) * 1e3
+
+
+KERNEL_TIMER: Optional[KernelTimer] = None
+
+
 def conv_gather(d: ConvDesc, x: torch.Tensor, w_packed: torch.Tensor, bias=None, mask=None, residual=None,
                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
     lib = L.load()
@@ -144,8 +160,15 @@ def conv_gather(d: ConvDesc, x: torch.Tensor, w_packed: torch.Tensor, bias=None,
     L.require_gpu_tensor(x, "x")
     L.require_gpu_tensor(w_packed, "w_packed")
     wp, wn = _ws(lib.fcd_conv_workspace_bytes(C.byref(d)), x.device)
+    timed = KERNEL_TIMER is not None and KERNEL_TIMER.match(d)
+    if timed:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     check(lib.fcd_conv_gather(C.byref(d), ptr(x), ptr(w_packed), ptr(bias), ptr(mask), ptr(residual), ptr(out),
                               wp, wn, stream()), "conv_gather")
+    if timed:
+        e1.record()
+        KERNEL_TIMER.pairs.append((e0, e1))
     return out
 
 
