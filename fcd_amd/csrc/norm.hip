@@ -37,12 +37,21 @@ ColPlan col_plan(int N, long HW, int C) {
   return p;
 }
 
+// The normalised + affine value of the forward pass.  in_apply_kernel and both backward kernels
+// evaluate this one expression, so the backward can re-derive the activation mask (value > 0) from
+// z instead of reading the forward's output again (tests compare against the mask taken from y).
+__device__ __forceinline__ float in_forward_value(float z, float mu, float rs, float ga, float be) {
+  return (z - mu) * rs * ga + be;
+}
+
 // partial[n][chunk][c][2] (double)
 template <int MODE>
 __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restrict__ x0, const float* __restrict__ x1,
                                                           const float* __restrict__ x2, const float* __restrict__ mean,
                                                           const float* __restrict__ rstd, double* __restrict__ partial,
-                                                          long HW, int C, ColPlan pl, float act_slope) {
+                                                          long HW, int C, ColPlan pl, float act_slope,
+                                                          const float* __restrict__ gamma = nullptr,
+                                                          const float* __restrict__ beta = nullptr) {
   extern __shared__ double sm[];   // [rows][C][2]
   const int n = blockIdx.y, chunk = blockIdx.x;
   const int c4b = pl.c4b, CB = c4b * 4;
@@ -53,12 +62,20 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restric
   if (active) {
     const long p0 = (long)chunk * pl.chunk_len;
     const long p1 = min(HW, p0 + pl.chunk_len);
-    float mu[4] = {0, 0, 0, 0}, rs[4] = {0, 0, 0, 0};
+    float mu[4] = {0, 0, 0, 0}, rs[4] = {0, 0, 0, 0}, ga[4] = {0, 0, 0, 0}, be[4] = {0, 0, 0, 0};
+    // x1 (the forward output y) is optional: with beta given the mask is recomputed from z, and a
+    // slope of 1 needs no mask at all
+    const bool need_mask = MODE == MODE_BWD && act_slope != 1.f;
+    const bool recompute = need_mask && beta != nullptr;
     if (MODE == MODE_BWD) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         mu[e] = mean[(long)n * C + cbase + tx * 4 + e];
         rs[e] = rstd[(long)n * C + cbase + tx * 4 + e];
+        if (recompute) {
+          ga[e] = gamma[cbase + tx * 4 + e];
+          be[e] = beta[cbase + tx * 4 + e];
+        }
       }
     }
     for (long px = p0 + ty; px < p1; px += pl.rows) {
@@ -75,9 +92,16 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restric
 #pragma unroll
         for (int e = 0; e < 4; ++e) s0[e] += av[e];
       } else {
-        const float4 y = *reinterpret_cast<const float4*>(x1 + off);
         const float4 z = *reinterpret_cast<const float4*>(x2 + off);
-        const float yv[4] = {y.x, y.y, y.z, y.w}, zv[4] = {z.x, z.y, z.z, z.w};
+        const float zv[4] = {z.x, z.y, z.z, z.w};
+        float yv[4] = {1.f, 1.f, 1.f, 1.f};
+        if (recompute) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) yv[e] = in_forward_value(zv[e], mu[e], rs[e], ga[e], be[e]);
+        } else if (need_mask) {
+          const float4 y = *reinterpret_cast<const float4*>(x1 + off);
+          yv[0] = y.x; yv[1] = y.y; yv[2] = y.z; yv[3] = y.w;
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float g1 = av[e] * (yv[e] > 0.f ? 1.f : act_slope);
@@ -182,10 +206,10 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const float* __restrict__
     const float4 ga = *reinterpret_cast<const float4*>(gamma + cc);
     const float4 be = *reinterpret_cast<const float4*>(beta + cc);
     float4 o;
-    o.x = (zv.x - mu.x) * rs.x * ga.x + be.x;
-    o.y = (zv.y - mu.y) * rs.y * ga.y + be.y;
-    o.z = (zv.z - mu.z) * rs.z * ga.z + be.z;
-    o.w = (zv.w - mu.w) * rs.w * ga.w + be.w;
+    o.x = in_forward_value(zv.x, mu.x, rs.x, ga.x, be.x);
+    o.y = in_forward_value(zv.y, mu.y, rs.y, ga.y, be.y);
+    o.z = in_forward_value(zv.z, mu.z, rs.z, ga.z, be.z);
+    o.w = in_forward_value(zv.w, mu.w, rs.w, ga.w, be.w);
     o.x = o.x > 0.f ? o.x : o.x * act_slope;
     o.y = o.y > 0.f ? o.y : o.y * act_slope;
     o.z = o.z > 0.f ? o.z : o.z * act_slope;
@@ -202,22 +226,30 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ z, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                            const float* __restrict__ s12, float* __restrict__ dz, long HW,
-                                                           int C, long total4, float act_slope, int use_running) {
+                                                           int C, long total4, float act_slope, int use_running,
+                                                           const float* __restrict__ beta) {
   const int c4 = C / 4;
   const float inv_hw = 1.f / (float)HW;
+  const bool need_mask = act_slope != 1.f;
+  const bool recompute = need_mask && beta != nullptr;
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total4; idx += (long)gridDim.x * 256) {
     const int cc = (int)(idx % c4) * 4;
     const long n = idx / ((long)HW * c4);
     const float4 g = *reinterpret_cast<const float4*>(gy + idx * 4);
-    const float4 yv = *reinterpret_cast<const float4*>(y + idx * 4);
     const float4 zv = *reinterpret_cast<const float4*>(z + idx * 4);
-    const float gv[4] = {g.x, g.y, g.z, g.w}, yy[4] = {yv.x, yv.y, yv.z, yv.w}, zz[4] = {zv.x, zv.y, zv.z, zv.w};
+    const float gv[4] = {g.x, g.y, g.z, g.w}, zz[4] = {zv.x, zv.y, zv.z, zv.w};
+    float yy[4] = {1.f, 1.f, 1.f, 1.f};
+    if (need_mask && !recompute) {
+      const float4 yv = *reinterpret_cast<const float4*>(y + idx * 4);
+      yy[0] = yv.x; yy[1] = yv.y; yy[2] = yv.z; yy[3] = yv.w;
+    }
     float o[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const long nc = n * C + cc + e;
-      const float g1 = gv[e] * (yy[e] > 0.f ? 1.f : act_slope);
       const float rs = rstd[nc];
+      if (recompute) yy[e] = in_forward_value(zz[e], mean[nc], rs, gamma[cc + e], beta[cc + e]);
+      const float g1 = gv[e] * (yy[e] > 0.f ? 1.f : act_slope);
       if (use_running) {
         o[e] = gamma[cc + e] * rs * g1;
       } else {
@@ -321,12 +353,14 @@ extern "C" int fcd_instnorm_apply(const float* z, const float* mean, const float
 }
 
 extern "C" int fcd_instnorm_bwd(const float* gy, const float* y, const float* z, const float* mean, const float* rstd,
-                                const float* gamma, float* dz, float* dgamma, float* dbeta, int accumulate, int N,
+                                const float* gamma, const float* beta, float* dz, float* dgamma, float* dbeta,
+                                int accumulate, int N,
                                 int HW, int C, float act_slope, int use_running, void* workspace,
                                 size_t workspace_bytes, void* stream) {
   int rc = check_nhwc("instnorm_bwd", N, HW, C);
   if (rc) return rc;
-  FCD_REQUIRE(gy && y && z && mean && rstd && gamma && dz, "instnorm_bwd: null tensor");
+  FCD_REQUIRE(gy && z && mean && rstd && gamma && dz, "instnorm_bwd: null tensor");
+  FCD_REQUIRE(y || beta || act_slope == 1.f, "instnorm_bwd: the activation mask needs y or beta");
   const size_t pb = partial_bytes(N, HW, C);
   if (!workspace || workspace_bytes < pb + (size_t)N * C * 2 * sizeof(float)) {
     fcd_set_error("instnorm_bwd: workspace too small");
@@ -338,7 +372,7 @@ extern "C" int fcd_instnorm_bwd(const float* gy, const float* y, const float* z,
   float* s12 = (float*)((char*)workspace + pb);
   const size_t shm = (size_t)pl.rows * pl.c4b * 4 * 2 * sizeof(double);
   hipLaunchKernelGGL((col_partial_kernel<MODE_BWD>), dim3(pl.chunks, N, pl.cblocks), dim3(256), shm, st, gy, y, z, mean, rstd,
-                     partial, (long)HW, C, pl, act_slope);
+                     partial, (long)HW, C, pl, act_slope, gamma, beta);
   rc = fcd_check_launch("instnorm_bwd/partial");
   if (rc) return rc;
   hipLaunchKernelGGL((finalize_kernel<FIN_BWD>), dim3(fcd_cdiv(C, 32), N), dim3(256), 0, st, (const double*)partial, s12,
@@ -353,7 +387,7 @@ extern "C" int fcd_instnorm_bwd(const float* gy, const float* y, const float* z,
   const long total4 = (long)N * HW * (C / 4);
   const int blocks = (int)std::min<long>(fcd_cdiv(total4, 256), 8192);
   hipLaunchKernelGGL(in_bwd_apply_kernel, dim3(blocks), dim3(256), 0, st, gy, y, z, mean, rstd, gamma, s12, dz, (long)HW,
-                     C, total4, act_slope, use_running);
+                     C, total4, act_slope, use_running, beta);
   return fcd_check_launch("instnorm_bwd/apply");
 }
 

@@ -256,10 +256,12 @@ class _GeneratorFn(torch.autograd.Function):
                 want_aff = needs[p0 + 1] or needs[p0 + 2]
                 sg, sb = grad_sink(ly.norm.weight, needs[p0 + 1]), grad_sink(ly.norm.bias, needs[p0 + 2])
                 direct = want_aff and sg is not None and sb is not None
-                dz, dgam, dbet = ops.instnorm_bwd(g, y if ly.res_from is None else z, z, mean, rstd,
+                # the ReLU mask is recomputed from z (beta given): the forward output is not read again
+                dz, dgam, dbet = ops.instnorm_bwd(g, None, z, mean, rstd,
                                                   ly.norm.weight.detach(), ly.act_slope, use_running,
                                                   want_affine=want_aff, dgamma=sg if direct else None,
-                                                  dbeta=sb if direct else None, accumulate=direct)
+                                                  dbeta=sb if direct else None, accumulate=direct,
+                                                  beta=ly.norm.bias.detach())
                 if not direct:
                     if needs[p0 + 1]:
                         grads[p0 + 1] = dgam

@@ -278,8 +278,9 @@ def instnorm_apply(z, mean, rstd, gamma, beta, act_slope: float, residual=None, 
 
 
 def instnorm_bwd(gy, y, z, mean, rstd, gamma, act_slope: float, use_running: bool, want_affine: bool = True,
-                 dgamma=None, dbeta=None, accumulate: bool = False):
-    """``dgamma`` / ``dbeta`` given: written (``accumulate``: added to) in place."""
+                 dgamma=None, dbeta=None, accumulate: bool = False, beta=None):
+    """``dgamma`` / ``dbeta`` given: written (``accumulate``: added to) in place.  ``beta`` given:
+    the activation mask is recomputed from ``z`` and ``y`` may be None."""
     n, h, w, c = z.shape
     lib = L.load()
     dz = torch.empty_like(z)
@@ -289,7 +290,7 @@ def instnorm_bwd(gy, y, z, mean, rstd, gamma, act_slope: float, use_running: boo
         dgamma = torch.empty_like(gamma)
         dbeta = torch.empty_like(gamma)
     wp, wn = _ws(lib.fcd_instnorm_workspace_bytes(n, h * w, c), z.device)
-    check(lib.fcd_instnorm_bwd(ptr(gy), ptr(y), ptr(z), ptr(mean), ptr(rstd), ptr(gamma), ptr(dz), ptr(dgamma),
+    check(lib.fcd_instnorm_bwd(ptr(gy), ptr(y), ptr(z), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(dz), ptr(dgamma),
                                ptr(dbeta), int(accumulate), n, h * w, c, act_slope, int(use_running), wp, wn, stream()),
           "instnorm_bwd")
     return dz, dgamma, dbeta

@@ -145,11 +145,14 @@ int fcd_instnorm_apply(const float* z, const float* mean, const float* rstd, con
 /* Backward.  g1 = gy * act'(y).  Pass 1 reduces s1[n][c] = sum g1, s2 = sum g1*xhat;
  * pass 2 writes dz = gamma*rstd*(g1 - s1/HW - xhat*s2/HW) (per-instance statistics) or
  * dz = gamma*rstd*g1 (use_running: eval-mode tracked norm), and
- * dgamma[c] (+)= sum_n s2, dbeta[c] (+)= sum_n s1. */
+ * dgamma[c] (+)= sum_n s2, dbeta[c] (+)= sum_n s1.
+ * The activation mask (y > 0) is taken from y, or - beta given, y may be NULL - recomputed
+ * from z with the forward's own expression (one tensor read less); act_slope 1 needs neither. */
 int fcd_instnorm_bwd(const float* gy, const float* y, const float* z, const float* mean,
-                     const float* rstd, const float* gamma, float* dz, float* dgamma, float* dbeta,
-                     int accumulate, int N, int HW, int C, float act_slope, int use_running,
-                     void* workspace, size_t workspace_bytes, void* stream);
+                     const float* rstd, const float* gamma, const float* beta, float* dz,
+                     float* dgamma, float* dbeta, int accumulate, int N, int HW, int C,
+                     float act_slope, int use_running, void* workspace, size_t workspace_bytes,
+                     void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Generator prologue / epilogue (fixed_point_gan.py:73-75 and :78-82).

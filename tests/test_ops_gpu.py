@@ -37,6 +37,11 @@ def test_instnorm_forward_backward(dev, shape, slope):
     dz, dg, db = ops.instnorm_bwd(nhwc(gy).to(dev), y_pre, zd, mean, rstd, gamma.detach().to(dev), slope, False)
     assert relerr(dz.cpu(), nhwc(z.grad)) <= 2e-5
     assert relerr(dg, gamma.grad) <= 2e-5 and relerr(db, beta.grad) <= 2e-5
+    # mask recomputed from z (beta given, no y): the same bits as with the mask taken from y
+    dz2, dg2, db2 = ops.instnorm_bwd(nhwc(gy).to(dev), None, zd, mean, rstd, gamma.detach().to(dev), slope, False,
+                                     beta=beta.detach().to(dev))
+    assert torch.equal(dz2, dz) and torch.equal(dg2, dg) and torch.equal(db2, db)
+    assert bool(((y_pre > 0) == (ops.instnorm_apply(zd, mean, rstd, gamma.detach().to(dev), beta.detach().to(dev), 1.0) > 0)).all())
 
 
 def test_instnorm_running_stats_and_eval(dev):
