@@ -222,42 +222,61 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const float* __restrict__
   }
 }
 
+// One block = one pixel chunk of one image, all channels: a thread keeps the per-(n, c) constants
+// of its 4 channels in registers and walks the chunk's pixels, so the streams are gy, z (and y only
+// when the mask is not recomputed) in, dz out.
 __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const float* __restrict__ gy, const float* __restrict__ y,
                                                            const float* __restrict__ z, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                            const float* __restrict__ s12, float* __restrict__ dz, long HW,
-                                                           int C, long total4, float act_slope, int use_running,
+                                                           int C, ColPlan pl, float act_slope, int use_running,
                                                            const float* __restrict__ beta) {
-  const int c4 = C / 4;
+  const int n = blockIdx.y, chunk = blockIdx.x;
+  const int c4b = pl.c4b;
+  const int cbase = blockIdx.z * 1024;
+  const int tx = threadIdx.x % c4b, ty = threadIdx.x / c4b;
+  if (ty >= pl.rows || cbase / 4 + tx >= pl.c4) return;
   const float inv_hw = 1.f / (float)HW;
   const bool need_mask = act_slope != 1.f;
   const bool recompute = need_mask && beta != nullptr;
-  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total4; idx += (long)gridDim.x * 256) {
-    const int cc = (int)(idx % c4) * 4;
-    const long n = idx / ((long)HW * c4);
-    const float4 g = *reinterpret_cast<const float4*>(gy + idx * 4);
-    const float4 zv = *reinterpret_cast<const float4*>(z + idx * 4);
+  const int c0 = cbase + tx * 4;
+  float mu[4], rs[4], ga[4], be[4], k0[4], k1[4], k2[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const long nc = (long)n * C + c0 + e;
+    mu[e] = mean[nc];
+    rs[e] = rstd[nc];
+    ga[e] = gamma[c0 + e];
+    be[e] = recompute ? beta[c0 + e] : 0.f;
+    k0[e] = ga[e] * rs[e];
+    k1[e] = use_running ? 0.f : s12[nc * 2] * inv_hw;
+    k2[e] = use_running ? 0.f : s12[nc * 2 + 1] * inv_hw;
+  }
+  const long p0 = (long)chunk * pl.chunk_len;
+  const long p1 = min(HW, p0 + pl.chunk_len);
+  for (long px = p0 + ty; px < p1; px += pl.rows) {
+    const long off = ((long)n * HW + px) * C + c0;
+    const float4 g = *reinterpret_cast<const float4*>(gy + off);
+    const float4 zv = *reinterpret_cast<const float4*>(z + off);
     const float gv[4] = {g.x, g.y, g.z, g.w}, zz[4] = {zv.x, zv.y, zv.z, zv.w};
     float yy[4] = {1.f, 1.f, 1.f, 1.f};
     if (need_mask && !recompute) {
-      const float4 yv = *reinterpret_cast<const float4*>(y + idx * 4);
+      const float4 yv = *reinterpret_cast<const float4*>(y + off);
       yy[0] = yv.x; yy[1] = yv.y; yy[2] = yv.z; yy[3] = yv.w;
     }
     float o[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const long nc = n * C + cc + e;
-      const float rs = rstd[nc];
-      if (recompute) yy[e] = in_forward_value(zz[e], mean[nc], rs, gamma[cc + e], beta[cc + e]);
+      if (recompute) yy[e] = in_forward_value(zz[e], mu[e], rs[e], ga[e], be[e]);
       const float g1 = gv[e] * (yy[e] > 0.f ? 1.f : act_slope);
       if (use_running) {
-        o[e] = gamma[cc + e] * rs * g1;
+        o[e] = k0[e] * g1;
       } else {
-        const float xh = (zz[e] - mean[nc]) * rs;
-        o[e] = gamma[cc + e] * rs * (g1 - s12[nc * 2] * inv_hw - xh * (s12[nc * 2 + 1] * inv_hw));
+        const float xh = (zz[e] - mu[e]) * rs[e];
+        o[e] = k0[e] * (g1 - k1[e] - xh * k2[e]);
       }
     }
-    *reinterpret_cast<float4*>(dz + idx * 4) = make_float4(o[0], o[1], o[2], o[3]);
+    *reinterpret_cast<float4*>(dz + off) = make_float4(o[0], o[1], o[2], o[3]);
   }
 }
 
@@ -384,10 +403,8 @@ extern "C" int fcd_instnorm_bwd(const float* gy, const float* y, const float* z,
     rc = fcd_check_launch("instnorm_bwd/affine");
     if (rc) return rc;
   }
-  const long total4 = (long)N * HW * (C / 4);
-  const int blocks = (int)std::min<long>(fcd_cdiv(total4, 256), 8192);
-  hipLaunchKernelGGL(in_bwd_apply_kernel, dim3(blocks), dim3(256), 0, st, gy, y, z, mean, rstd, gamma, s12, dz, (long)HW,
-                     C, total4, act_slope, use_running, beta);
+  hipLaunchKernelGGL(in_bwd_apply_kernel, dim3(pl.chunks, N, pl.cblocks), dim3(256), 0, st, gy, y, z, mean, rstd, gamma, s12,
+                     dz, (long)HW, C, pl, act_slope, use_running, beta);
   return fcd_check_launch("instnorm_bwd/apply");
 }
 
