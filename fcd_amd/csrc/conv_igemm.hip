@@ -36,15 +36,6 @@ struct GatherArgs {
   int tap_inner;   // K-tiles run taps-inside-channel-slices (needs Cin % 32 == 0)
 };
 
-__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
-  unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
-  ua = (ua + 0x7FFFu + ((ua >> 16) & 1u)) >> 16;
-  ub = (ub + 0x7FFFu + ((ub >> 16) & 1u)) & 0xFFFF0000u;
-  return ua | ub;
-}
-
-__device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-
 __device__ __forceinline__ float epilogue_value(float v, int co, long o, const GatherArgs& p) {
   if (p.bias) v += p.bias[co];
   v = v > 0.f ? v : v * p.act_slope;
@@ -124,7 +115,6 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs p) {
 // gfx950: tools/probe_lds_dma_oob.hip).  No staging registers, no ds_write, one barrier per
 // K-tile, counted vmcnt so the prefetch stays in flight across the barrier.
 // ============================================================================================
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
 constexpr unsigned OOB = 0x80000000u;   // beyond any tensor this library accepts (< 2 GiB)
 
 template <int N>
@@ -874,9 +864,6 @@ int validate_conv(const FcdConvDesc* d) {
 // tile shape by problem shape (shared by the workspace query and the launch)
 void gather_tile(const FcdConvDesc* d, int& bm, int& bn) {
   const long M = (long)d->N * d->GH * d->GW;
-  if (const char* e = getenv("FCD_TILE")) {   // tuning aid: "128x64" etc.
-    if (sscanf(e, "%dx%d", &bm, &bn) == 2) return;
-  }
   if (d->Cout <= 16 && d->precision == FCD_PREC_F32) { bm = 128; bn = 16; }   // 16-wide MFMA tiles
   else if (d->Cout <= 32) { bm = 128; bn = 32; }
   else if (d->Cout <= 64) { bm = 128; bn = 64; }
