@@ -34,6 +34,8 @@ struct GatherArgs {
   long w_phase_stride;
   float act_slope, mask_slope;
   int tap_inner;   // K-tiles run taps-inside-channel-slices (needs Cin % 32 == 0)
+  double* stats;   // optional [N][nphase*stats_cpp][CoutP][2]: per-wave column sums of the output (IN statistics)
+  int stats_cpp;   // wave row-chunks per phase per image = GH*GW / WTM
 };
 
 __device__ __forceinline__ float epilogue_value(float v, int co, long o, const GatherArgs& p) {
@@ -473,6 +475,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
       }
     return;
   }
+  // optional InstanceNorm statistics of the tile just computed: per-wave column sums (sum, sum of
+  // squares over the wave's WTM rows, which lie in one image), written as double partials for
+  // finalize_kernel<FIN_STATS>; saves the separate read of the output tensor
+  float ssum[TN], qsum[TN];
+#pragma unroll
+  for (int ni = 0; ni < TN; ++ni) ssum[ni] = qsum[ni] = 0.f;
 #pragma unroll
   for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
@@ -515,7 +523,33 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
 #pragma unroll
       for (int r = 0; r < 16; ++r)
         if (off[r] >= 0) dst[off[r] + co] = v[r];
+      if (p.stats) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (off[r] >= 0) {
+            ssum[ni] += v[r];
+            qsum[ni] += v[r] * v[r];
+          }
+      }
     }
+  if (p.stats) {
+    const int m0 = tm * BM + wm * WTM;
+    if (m0 < p.M) {
+      const int n = m0 / ghw, local = (m0 - n * ghw) / WTM;
+      const long chunk = (long)n * p.nphase * p.stats_cpp + (long)phase * p.stats_cpp + local;
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni) {
+        const float s2 = ssum[ni] + __shfl_xor(ssum[ni], 32);
+        const float q2 = qsum[ni] + __shfl_xor(qsum[ni], 32);
+        const int co = tn * BN + wn * WTN + ni * 32 + lr;
+        if (lh == 0 && co < p.CoutP) {
+          double* d2 = p.stats + (chunk * p.CoutP + co) * 2;
+          d2[0] = (double)s2;
+          d2[1] = (double)q2;
+        }
+      }
+    }
+  }
 }
 
 template <int T>
@@ -905,6 +939,8 @@ void fill_gather_args(const FcdConvDesc* d, GatherArgs& a) {
   a.w_phase_stride = (long)d->Cout * a.K;
   a.act_slope = d->act_slope; a.mask_slope = d->mask_slope;
   a.tap_inner = (d->Cin % 32 == 0 && d->KH * d->KW > 1) ? 1 : 0;
+  a.stats = nullptr;
+  a.stats_cpp = 0;
 
 }
 
@@ -917,24 +953,16 @@ extern "C" size_t fcd_conv_workspace_bytes(const FcdConvDesc* d) {
   return (size_t)d->nphase * sk * d->N * d->GH * d->GW * d->CoutP * sizeof(float);
 }
 
-extern "C" int fcd_conv_gather(const FcdConvDesc* d, const float* in, const float* w_packed,
-                               const float* bias, const float* mask_src, const float* residual,
-                               float* out, void* workspace, size_t workspace_bytes, void* stream) {
-  int rc = validate_conv(d);
-  if (rc) return rc;
-  FCD_REQUIRE(in && w_packed && out, "conv: null tensor");
-  FCD_REQUIRE(((uintptr_t)in % 16) == 0 && ((uintptr_t)w_packed % 16) == 0, "conv: operands must be 16-byte aligned");
-  const size_t need = fcd_conv_workspace_bytes(d);
-  if (need > 0 && (workspace == nullptr || workspace_bytes < need)) {
-    fcd_set_error("conv: workspace %zu < %zu bytes", workspace_bytes, need);
-    return FCD_EWORKSPACE;
-  }
-  GatherArgs a;
-  fill_gather_args(d, a);
-  a.in = in; a.w = w_packed; a.bias = bias; a.mask = mask_src; a.res = residual; a.out = out;
-  a.slab = (float*)workspace;
-  hipStream_t st = fcd_stream(stream);
-  int bm, bn;
+namespace {
+
+// rows of the output tile one wavefront owns (the granularity of the fused statistics)
+int gather_wave_rows(int bm, int bn) {
+  if (bm == 128 && bn == 128) return 64;
+  return 32;
+}
+
+int run_gather(const FcdConvDesc* d, GatherArgs& a, hipStream_t st) {
+  int bm, bn, rc;
   gather_tile(d, bm, bn);
   a.tiles_m = fcd_cdiv(a.M, bm);
   a.tiles_n = fcd_cdiv(d->Cout, bn);
@@ -957,6 +985,85 @@ extern "C" int fcd_conv_gather(const FcdConvDesc* d, const float* in, const floa
     rc = fcd_check_launch("conv_splitk_reduce");
   }
   return rc;
+}
+
+// chunks per image when the statistics can ride in the epilogue, else 0
+int fused_stats_chunks(const FcdConvDesc* d) {
+  int bm, bn;
+  gather_tile(d, bm, bn);
+  if (bn == 16 || resolve_splitk(d) != 1) return 0;
+  const int wtm = gather_wave_rows(bm, bn);
+  const long ghw = (long)d->GH * d->GW;
+  if (ghw % wtm) return 0;
+  return (int)(d->nphase * (ghw / wtm));
+}
+
+}  // namespace
+
+extern "C" int fcd_conv_gather(const FcdConvDesc* d, const float* in, const float* w_packed,
+                               const float* bias, const float* mask_src, const float* residual,
+                               float* out, void* workspace, size_t workspace_bytes, void* stream) {
+  int rc = validate_conv(d);
+  if (rc) return rc;
+  FCD_REQUIRE(in && w_packed && out, "conv: null tensor");
+  FCD_REQUIRE(((uintptr_t)in % 16) == 0 && ((uintptr_t)w_packed % 16) == 0, "conv: operands must be 16-byte aligned");
+  const size_t need = fcd_conv_workspace_bytes(d);
+  if (need > 0 && (workspace == nullptr || workspace_bytes < need)) {
+    fcd_set_error("conv: workspace %zu < %zu bytes", workspace_bytes, need);
+    return FCD_EWORKSPACE;
+  }
+  GatherArgs a;
+  fill_gather_args(d, a);
+  a.in = in; a.w = w_packed; a.bias = bias; a.mask = mask_src; a.res = residual; a.out = out;
+  a.slab = (float*)workspace;
+  return run_gather(d, a, fcd_stream(stream));
+}
+
+extern "C" size_t fcd_conv_gather_stats_workspace_bytes(const FcdConvDesc* d) {
+  if (!d || d->nphase < 1 || d->Cin <= 0 || d->KH <= 0 || d->KW <= 0 || d->N <= 0) return 0;
+  const long hw = (long)d->OH * d->OW;
+  const int chunks = fused_stats_chunks(d);
+  size_t stats = fcd_instnorm_workspace_bytes(d->N, (int)hw, d->CoutP);
+  if (chunks > 0) stats = std::max(stats, (size_t)d->N * chunks * d->CoutP * 2 * sizeof(double));
+  const size_t conv = (fcd_conv_workspace_bytes(d) + 255) / 256 * 256;
+  return conv + stats;
+}
+
+extern "C" int fcd_conv_gather_stats(const FcdConvDesc* d, const float* in, const float* w_packed, float* out,
+                                     float* mean, float* rstd, float* var_unbiased, float eps, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+  int rc = validate_conv(d);
+  if (rc) return rc;
+  FCD_REQUIRE(in && w_packed && out && mean && rstd, "conv_stats: null tensor");
+  FCD_REQUIRE(((uintptr_t)in % 16) == 0 && ((uintptr_t)w_packed % 16) == 0, "conv: operands must be 16-byte aligned");
+  FCD_REQUIRE(d->act_slope == 1.f, "conv_stats: the convolution in front of an InstanceNorm has no activation");
+  FCD_REQUIRE((long)d->N * d->GH * d->GW * d->nphase == (long)d->N * d->OH * d->OW,
+              "conv_stats: the phases must cover the output exactly once");
+  const size_t need = fcd_conv_gather_stats_workspace_bytes(d);
+  if (workspace == nullptr || workspace_bytes < need) {
+    fcd_set_error("conv_stats: workspace %zu < %zu bytes", workspace_bytes, need);
+    return FCD_EWORKSPACE;
+  }
+  const size_t conv_ws = (fcd_conv_workspace_bytes(d) + 255) / 256 * 256;
+  void* stats_ws = (char*)workspace + conv_ws;
+  hipStream_t st = fcd_stream(stream);
+  GatherArgs a;
+  fill_gather_args(d, a);
+  a.in = in; a.w = w_packed; a.bias = nullptr; a.mask = nullptr; a.res = nullptr; a.out = out;
+  a.slab = (float*)workspace;
+  const int chunks = fused_stats_chunks(d);
+  const long hw = (long)d->OH * d->OW;
+  if (chunks == 0) {   // shape does not allow the fused form: convolution, then the two-pass statistics
+    rc = run_gather(d, a, st);
+    if (rc) return rc;
+    return fcd_instnorm_stats(out, mean, rstd, var_unbiased, d->N, (int)hw, d->CoutP, eps, stats_ws,
+                              workspace_bytes - conv_ws, stream);
+  }
+  a.stats = (double*)stats_ws;
+  a.stats_cpp = chunks / d->nphase;
+  rc = run_gather(d, a, st);
+  if (rc) return rc;
+  return fcd_finalize_stats((const double*)stats_ws, mean, rstd, var_unbiased, d->N, hw, d->CoutP, chunks, eps, st);
 }
 
 static int wgrad_bm(const FcdWgradDesc* d) { return d->O <= 32 ? 32 : (d->O <= 64 ? 64 : (d->O <= 128 ? 128 : 256)); }

@@ -11,6 +11,11 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
 void fcd_set_error(const char* fmt, ...);
 
+// norm.hip: second stage of the InstanceNorm statistics on partial[N][chunks][C][2] doubles
+// (used by the convolution's fused-statistics entry point in conv_igemm.hip).
+int fcd_finalize_stats(const double* partial, float* mean, float* rstd, float* var_unbiased, int N, long HW, int C,
+                       int chunks, float eps, hipStream_t st);
+
 #define FCD_REQUIRE(cond, ...)            \
   do {                                    \
     if (!(cond)) {                        \

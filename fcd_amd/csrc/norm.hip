@@ -316,6 +316,13 @@ size_t partial_bytes(int N, long HW, int C) {
 
 }  // namespace
 
+int fcd_finalize_stats(const double* partial, float* mean, float* rstd, float* var_unbiased, int N, long HW, int C,
+                       int chunks, float eps, hipStream_t st) {
+  hipLaunchKernelGGL((finalize_kernel<FIN_STATS>), dim3(fcd_cdiv(C, 32), N), dim3(256), 0, st, partial, mean, rstd,
+                     var_unbiased, HW, C, chunks, eps, 0);
+  return fcd_check_launch("instnorm_stats/finalize");
+}
+
 extern "C" size_t fcd_instnorm_workspace_bytes(int N, int HW, int C) {
   if (N <= 0 || HW <= 0 || C <= 0 || C % 4) return 0;
   return partial_bytes(N, HW, C) + (size_t)N * C * 2 * sizeof(float) + 64;

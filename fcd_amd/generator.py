@@ -190,26 +190,29 @@ class _GeneratorFn(torch.autograd.Function):
             pi += 1
             a = acts[-1]
             g = ly.geom
+            nm = ly.norm
+            use_running = nm is not None and nm.track and not training
+            fuse = nm is not None and not use_running      # statistics ride in the conv's epilogue
             if ly.kind == "conv":
                 d = g.fwd_desc(n, a.shape[1], a.shape[2], precision=prec)
-                z = ops.conv_gather(d, a, ly.conv.packed("fwd", g))
+                wp = ly.conv.packed("fwd", g)
             else:
                 d = g.adj_desc(n, a.shape[1], a.shape[2], precision=prec)
-                z = ops.conv_gather(d, a, ly.conv.packed("adj", g))
-            if ly.norm is None:
+                wp = ly.conv.packed("adj", g)
+            if fuse:
+                z, mean, rstd, varu = ops.conv_gather_stats(d, a, wp, want_var=nm.track)
+            else:
+                z = ops.conv_gather(d, a, wp)
+            if nm is None:
                 saved.append((z, None, None, False))
                 acts.append(z)
                 continue
             gamma, beta = params[pi], params[pi + 1]
             pi += 2
-            nm = ly.norm
-            use_running = nm.track and not training
             if use_running:
                 mean, rstd = ops.instnorm_stats_from_running(nm.running_mean, nm.running_var, n)
-            else:
-                mean, rstd, varu = ops.instnorm_stats(z, want_var=nm.track)
-                if nm.track:
-                    ops.instnorm_update_running(nm.running_mean, nm.running_var, mean, varu)
+            elif nm.track:
+                ops.instnorm_update_running(nm.running_mean, nm.running_var, mean, varu)
             res = acts[li + 1 + ly.res_from] if ly.res_from is not None else None
             y = ops.instnorm_apply(z, mean, rstd, gamma.detach(), beta.detach(), ly.act_slope, residual=res)
             saved.append((z, mean, rstd, use_running))

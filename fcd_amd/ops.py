@@ -172,6 +172,26 @@ def conv_gather(d: ConvDesc, x: torch.Tensor, w_packed: torch.Tensor, bias=None,
     return out
 
 
+def conv_gather_stats(d: ConvDesc, x: torch.Tensor, w_packed: torch.Tensor, want_var: bool = False):
+    """Convolution + InstanceNorm statistics of its output: ``(z, mean, rstd, var_unbiased)``."""
+    lib = L.load()
+    exp_in = (d.N, d.IH, d.IW, d.Cin)
+    if tuple(x.shape) != exp_in:
+        raise RuntimeError(f"conv_gather_stats: input {tuple(x.shape)} != descriptor {exp_in}")
+    if w_packed.numel() != d.nphase * d.Cout * d.KH * d.KW * d.Cin:
+        raise RuntimeError("conv_gather_stats: packed weight size")
+    L.require_gpu_tensor(x, "x")
+    L.require_gpu_tensor(w_packed, "w_packed")
+    out = torch.empty((d.N, d.OH, d.OW, d.CoutP), dtype=torch.float32, device=x.device)
+    mean = torch.empty((d.N, d.CoutP), dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    varu = torch.empty_like(mean) if want_var else None
+    wp, wn = _ws(lib.fcd_conv_gather_stats_workspace_bytes(C.byref(d)), x.device)
+    check(lib.fcd_conv_gather_stats(C.byref(d), ptr(x), ptr(w_packed), ptr(out), ptr(mean), ptr(rstd), ptr(varu), IN_EPS,
+                                    wp, wn, stream()), "conv_gather_stats")
+    return out, mean, rstd, varu
+
+
 def conv_wgrad(d: WgradDesc, gsmall: torch.Tensor, xbig: torch.Tensor, dw: Optional[torch.Tensor] = None) -> torch.Tensor:
     lib = L.load()
     if tuple(gsmall.shape) != (d.N, d.GH, d.GW, d.OP):

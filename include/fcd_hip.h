@@ -82,6 +82,17 @@ int fcd_conv_gather(const FcdConvDesc* d, const float* in, const float* w_packed
                     const float* bias, const float* mask_src, const float* residual,
                     float* out, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The convolution in front of an InstanceNorm (no bias, no activation) together with that norm's
+ * statistics: out as fcd_conv_gather, and mean[n][c], rstd[n][c] (and, if not NULL, the unbiased
+ * variance for the running-stat update) as fcd_instnorm_stats of out
+ * (fixed_point_gan.py:27-28, 45-46, 52-53, 63-64: Conv2d / ConvTranspose2d + InstanceNorm2d).
+ * Where the tile shape allows, the per-channel sums are taken from the accumulators in the
+ * convolution's epilogue (out is not read again); otherwise this is the two calls in a row. */
+size_t fcd_conv_gather_stats_workspace_bytes(const FcdConvDesc* d);
+int fcd_conv_gather_stats(const FcdConvDesc* d, const float* in, const float* w_packed, float* out,
+                          float* mean, float* rstd, float* var_unbiased, float eps, void* workspace,
+                          size_t workspace_bytes, void* stream);
+
 /* Weight gradient of the same convolution family:
  *   dw[o][i][kh][kw] (+)= sum_{n,a,b} gsmall[n,a,b,o] *
  *                          xbig[n, a*stride - pad + kh, b*stride - pad + kw, i]

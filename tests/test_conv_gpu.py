@@ -107,3 +107,42 @@ def test_conv_wgrad(dev, geom, prec):
     d.splitk = 2
     dw2 = ops.conv_wgrad(d, to_nhwc(gy, g.OP).to(dev), to_nhwc(x, g.IP).to(dev), dw.clone())
     assert relerr(dw2.cpu(), 2 * ref) <= TOL[prec]
+
+
+# (O, I, k, s, p, N, H, W, form): shapes where the statistics ride in the epilogue (H*W a multiple of the
+# wave's rows, no split-K) and shapes that fall back to the two-pass path
+STAT_GEOMS = [
+    (256, 256, 3, 1, 1, 4, 32, 32, "fwd"),     # residual-block conv: fused, 128x128 tiles
+    (64, 11, 7, 1, 3, 2, 32, 32, "fwd"),       # first conv: fused, 128x64 tiles
+    (128, 64, 4, 2, 1, 2, 32, 32, "fwd"),      # down-sampling
+    (128, 64, 4, 2, 1, 2, 16, 16, "adj"),      # ConvTranspose2d (four phases)
+    (96, 40, 3, 1, 1, 1, 9, 7, "fwd"),         # ragged: fallback
+    (512, 256, 4, 2, 1, 4, 4, 4, "fwd"),       # split-K: fallback
+]
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("geom", STAT_GEOMS)
+def test_conv_with_fused_instnorm_statistics(dev, geom, prec):
+    """fcd_conv_gather_stats == fcd_conv_gather followed by fcd_instnorm_stats."""
+    from fcd_amd import ops
+    O, I, k, s, p, N, H, W, form = geom
+    g = ops.ConvGeom(O, I, k, s, p)
+    torch.manual_seed(4)
+    w = torch.randn(O, I, k, k) / (I * k * k) ** 0.5
+    if form == "fwd":
+        x = to_nhwc(torch.randn(N, I, H, W) + 0.3, g.IP).to(dev)
+        d = g.fwd_desc(N, H, W, precision=prec)
+        wp = ops.pack_weight_fwd(w.to(dev), g)
+    else:
+        x = to_nhwc(torch.randn(N, O, H, W) + 0.3, g.OP).to(dev)
+        d = g.adj_desc(N, H, W, precision=prec)
+        wp = ops.pack_weight_adj(w.to(dev), g)
+    z0 = ops.conv_gather(d, x, wp)
+    m0, r0, v0 = ops.instnorm_stats(z0, want_var=True)
+    z1, m1, r1, v1 = ops.conv_gather_stats(d, x, wp, want_var=True)
+    assert torch.equal(z0, z1)
+    assert relerr(m1, m0) <= 1e-5 and relerr(r1, r0) <= 1e-5 and relerr(v1, v0) <= 1e-5
+    zc = z1.cpu().double()
+    assert relerr(m1, zc.mean((1, 2))) <= 1e-5
+    assert relerr(v1, zc.var((1, 2), unbiased=True)) <= 1e-5
