@@ -49,6 +49,22 @@ def f1_score(cm: np.ndarray) -> float:
     return float(np.mean(f1s))
 
 
+def iou_score(cm: np.ndarray) -> float:
+    """Mean IoU of ``cm[truth][prediction]`` (``metrics.py:16-28``; an empty class scores 1)."""
+    ious = []
+    for i in range(cm.shape[0]):
+        tp = int(cm[i, i])
+        denom = int(cm[:, i].sum()) + int(cm[i, :].sum()) - tp
+        ious.append(1 if denom == 0 else float(tp) / denom)
+    return float(np.mean(ious))
+
+
+def accuracy(cm: np.ndarray) -> float:
+    """Overall accuracy (``metrics.py`` ``accuracy``): trace / total."""
+    total = int(cm.sum())
+    return float(np.trace(cm)) / total if total else 1.0
+
+
 def best_threshold_from_hist(hist: np.ndarray, thresholds: np.ndarray) -> float:
     """The reference's sweep (``fcd_solver.py:713-721``: keep going while F1 does not drop) on the
     device histogram: ``hist[cls][j]`` = valid pixels of class ``cls`` predicted 1 for exactly the
@@ -147,6 +163,7 @@ class FCDSolver(nn.Module):
         self.grad_sync = None                       # parallel.GradSync when data-parallel
         self.overlap_comm = True                    # overlap D's gradient all-reduce with the G step's start
         self._pending = None
+        self._val_cm = None
         self.build_model()
         self.D.register_forward_pre_hook(self._flush_pending)
         self.set_precision(getattr(config, "precision", "fp32"))
@@ -330,6 +347,29 @@ class FCDSolver(nn.Module):
         self._flush_pending()          # no G update this step: nothing used D in between
         self.global_step += 1
         return d_loss, g_loss
+
+    # ---------------------------------------------------------------- validation --------
+    @torch.no_grad()
+    def validation_step(self, batch, batch_idx=0):
+        """``fcd_solver.py:497-519``: difference map, ``> self.threshold`` (fp32 compare), confusion
+        counts over pixels with ``target > 0`` (class = target - 1).  The counts are accumulated
+        on the device (``fcd_threshold_hist`` with the single threshold); nothing is copied back
+        per batch."""
+        x_real, target = batch[0], batch[-1]
+        dev = self.device
+        if self._val_cm is None:
+            self._val_cm = torch.zeros((2, 2), dtype=torch.int64, device=dev)
+            self._val_thr = torch.tensor([self.threshold], dtype=torch.float32, device=dev)
+        difference = self.compute_difference_map(x_real.to(dev))
+        ops.threshold_hist(difference, target.to(dev).to(torch.uint8).contiguous(), self._val_thr, self._val_cm)
+
+    def validation_epoch_end(self, val_step_outputs=None):
+        """Confusion matrix ``cm[truth][prediction]`` and the reference's printed metrics
+        (``fcd_solver.py:523-544``, ``metrics.py``); resets the accumulator."""
+        cm = np.zeros((2, 2), dtype=np.int64) if self._val_cm is None else self._val_cm.cpu().numpy()
+        self._val_cm = None
+        # the figures of the reference's "Validation Result" line (metrics.accuracy / iou_score / f1_score)
+        return {"confusion_matrix": cm, "Accuracy": accuracy(cm), "IoU": iou_score(cm), "F1": f1_score(cm)}
 
     # ---------------------------------------------------------------- inference ---------
     @torch.no_grad()

@@ -147,3 +147,28 @@ def test_find_best_threshold_on_device(dev):
     ops.valid_minmax(dd, tt, mm)
     assert float(mm[0]) == float(preds.min()) and float(mm[1]) == float(preds.max())
     assert best_threshold_from_hist(h, thresholds) is not None
+
+
+def test_validation_step_confusion_matrix(dev):
+    """validation_step / validation_epoch_end (fcd_solver.py:497-544): device confusion counts equal
+    numpy's on the same difference maps; metrics as metrics.py computes them."""
+    s = tiny_solver(dev)
+    s.G.eval()
+    s.threshold = 0.05
+    batch, _ = O.synth_batch(4, 32, 10)
+    x = batch[0]
+    rng = np.random.default_rng(11)
+    tgt = rng.integers(0, 3, size=(4, 32, 32)).astype(np.uint8)
+    cm_ref = np.zeros((2, 2), dtype=np.int64)
+    for i in (0, 2):
+        xb, tb = x[i:i + 2], torch.from_numpy(tgt[i:i + 2])
+        s.validation_step((xb, None, None, None, None, tb))
+        d = s.compute_difference_map(xb.to(dev)).cpu().numpy()
+        pred = (d > np.float32(s.threshold)).astype(np.uint8)
+        valid = tgt[i:i + 2] > 0
+        cm_ref += O.compute_confusion_matrix(pred[valid], tgt[i:i + 2][valid] - 1, 2)
+    out = s.validation_epoch_end()
+    assert np.array_equal(out["confusion_matrix"], cm_ref) and cm_ref.sum() == int((tgt > 0).sum())
+    assert out["F1"] == O.f1_score(cm_ref)
+    assert abs(out["Accuracy"] - np.diag(cm_ref).sum() / cm_ref.sum()) < 1e-15
+    assert s.validation_epoch_end()["confusion_matrix"].sum() == 0      # accumulator was reset
