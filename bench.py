@@ -24,7 +24,7 @@ sys.path.insert(0, ROOT)
 BASE = dict(batch=16, size=128, bands=10, c_dim=1, conv_dim=64, g_repeat=6, d_repeat=6)
 # algorithmic work per image of one G+D step: 12+1 G passes, 15 D passes
 GFLOP_PER_IMG = 293.72
-PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0}   # MI355X_MICROARCH.md dense MFMA peaks
+PEAK_TFLOPS = {"fp32": 157.3, "fp32x3": 157.3, "bf16": 2500.0}   # MI355X_MICROARCH.md dense MFMA peaks
 
 
 def is_dominant(d):
@@ -44,7 +44,7 @@ def dominant_kernel_roofline(precision, dev, in_step_us=None, in_step_launches=0
     x = torch.randn(n, h, w, 256, device=dev)
     wt = torch.randn(256, 256, 3, 3, device=dev) / 48.0
     wf = ops.pack_weight_fwd(wt, g)
-    prec = L.PREC_BF16 if precision == "bf16" else L.PREC_F32
+    prec = {"fp32": L.PREC_F32, "fp32x3": L.PREC_BF16X3, "bf16": L.PREC_BF16}[precision]
     d = g.fwd_desc(n, h, w, precision=prec)
     out = ops.conv_gather(d, x, wf)
     for _ in range(3):
@@ -64,7 +64,7 @@ def dominant_kernel_roofline(precision, dev, in_step_us=None, in_step_launches=0
     # HBM-side bytes per launch of this same launch from the rocprofv3 PMC passes committed under
     # profiles/r1_e_resblock_conv_pmc_*.csv: FETCH_SIZE 17507 KB x 2 (gfx950 correction) + WRITE_SIZE
     # 16384 KB; algorithmic: 16.8 MB input + 2.4 MB weights + 16.8 MB output.  fp32 launch only.
-    traffic = 2 * 17507 * 1024 + 16384 * 1024 if precision == "fp32" else None
+    traffic = 2 * 17507 * 1024 + 16384 * 1024 if precision in ("fp32", "fp32x3") else None
     return {"bound": "mfma", "kernel": "conv_gather_dma_kernel<128,128> 3x3 256->256 @32x32 B16",
             "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
             "us_per_launch": round(ms * 1e3, 2), "launches_timed": in_step_launches,
@@ -146,7 +146,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--precision", default=os.environ.get("FCD_PRECISION", "fp32"), choices=["fp32", "bf16"])
+    ap.add_argument("--precision", default=os.environ.get("FCD_PRECISION", "fp32"), choices=["fp32", "fp32x3", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default=os.environ.get("FCD_DIST_BACKEND", "nccl"),
                     help="torch.distributed backend: nccl (= RCCL over xGMI); gloo only to rehearse the "
@@ -226,7 +226,7 @@ def main():
         res = {"metric": "FCD train images/sec (G+D step, 128x128 multispectral)", "value": round(value, 2),
                "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "fp32" if args.precision == "fp32" else "bf16",
+               "dtype": "bf16" if args.precision == "bf16" else "fp32",
                "data": "synthetic (numpy PCG64 uint16 patches -> [-1,1], nodata rectangle; random-init weights)",
                "config": {"workload": "FCD G+D train step incl. gradient penalty, batch 16/GPU, 128x128x10, "
                                       "6 res blocks, D x6 (BASELINE.json configs[1])",

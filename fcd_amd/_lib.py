@@ -18,6 +18,7 @@ LIB_PATH = os.path.join(_HERE, "libfcd_hip.so")
 
 PREC_F32 = 0
 PREC_BF16 = 1
+PREC_BF16X3 = 2
 
 c_float_p = C.c_void_p  # device pointers travel as opaque addresses
 

@@ -119,6 +119,38 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs p) {
 // ============================================================================================
 constexpr unsigned OOB = 0x80000000u;   // beyond any tensor this library accepts (< 2 GiB)
 
+// fp32 -> three bf16 pieces with f == h + m + l up to 2^-24 |f| (the residuals f - h and (f - h) - m
+// are exact in fp32).  Six bf16 MFMAs over the piece pairs
+// (hh, hm, mh, hl, lh, mm) reproduce an fp32 product to ~2^-23 relative: fp32-faithful results at the
+// bf16 matrix rate (FCD_PREC_BF16X3).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// two fp32 -> one dword of two bf16 (round to nearest even); asm because the packed form is what
+// keeps the split at 5.5 VALU operations per value (the generic vector conversion re-converts
+// every element once more for the residual)
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+
+__device__ __forceinline__ void split3(const f32x8 f, bf16x8_t& h, bf16x8_t& m, bf16x8_t& l) {
+  // round-to-nearest at every level (unbiased: a truncating split leaves every dropped term with the
+  // sign of the product, which adds up coherently through the network); both residuals are exact
+  u32x4 hp, mp, lp;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float a0 = f[2 * i], a1 = f[2 * i + 1];
+    hp[i] = cvt_pk_bf16(a0, a1);
+    const float r0 = a0 - __uint_as_float(hp[i] << 16), r1 = a1 - __uint_as_float(hp[i] & 0xFFFF0000u);
+    mp[i] = cvt_pk_bf16(r0, r1);
+    const float s0 = r0 - __uint_as_float(mp[i] << 16), s1 = r1 - __uint_as_float(mp[i] & 0xFFFF0000u);
+    lp[i] = cvt_pk_bf16(s0, s1);
+  }
+  h = __builtin_bit_cast(bf16x8_t, hp);
+  m = __builtin_bit_cast(bf16x8_t, mp);
+  l = __builtin_bit_cast(bf16x8_t, lp);
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   static_assert(N >= 0 && N <= 16, "vmcnt immediate");
@@ -184,10 +216,10 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 
 // N16: the output-channel tile is 16 wide (v_mfma_f32_16x16x4_f32) for the 10/12-channel image
 // layers; the B stage keeps its 32-row LDS slot, rows 16.. are loaded as zeros and never read.
-template <int BM, int BN, int WM, int WN, int S, bool BF16, bool N16 = false>
+template <int BM, int BN, int WM, int WN, int S, int PREC, bool N16 = false>
 __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const GatherArgs p, const unsigned in_bytes,
                                                                        const unsigned w_bytes) {
-  static_assert(!N16 || (BN == 32 && WN == 1 && !BF16), "N16 shape");
+  static_assert(!N16 || (BN == 32 && WN == 1 && PREC == FCD_PREC_F32), "N16 shape");
   constexpr int BNC = N16 ? 16 : BN;            // output channels this block computes
   constexpr int NW = WM * WN, NT = 64 * NW;     // 4 waves (one per SIMD) or 8 (two per SIMD)
   constexpr int WTM = BM / WM, WTN = BN / WN;
@@ -319,6 +351,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  f32x16 acc2[PREC == FCD_PREC_BF16X3 ? TM : 1][PREC == FCD_PREC_BF16X3 ? TN : 1];   // small terms (BF16X3)
+  if constexpr (PREC == FCD_PREC_BF16X3) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[i][j][r] = 0.f;
+  }
   constexpr int TM16 = WTM / 16;
   f32x4 acc16[TM16];
 #pragma unroll
@@ -370,7 +411,45 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
               if (q * (8 * TM16) / ND == g) issue_one(q);
           }
       }
-    } else if constexpr (BF16) {
+    } else if constexpr (PREC == FCD_PREC_BF16X3) {
+      // fp32-faithful on the bf16 pipe: same fragment reads as the bf16 path, each operand split
+      // into three bf16 pieces in registers, six MFMAs per tile and k16-step
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        bf16x8_t ah[TM], am[TM], al[TM], bh[TN], bm2[TN], bl[TN];
+        const int c0 = 4 * s2 + 2 * lh;
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+          const int r = wm * WTM + mi * 32 + lr, sw = (r >> 1) & 7;
+          const float4 lo = As[r * 8 + (c0 ^ sw)], hi = As[r * 8 + ((c0 + 1) ^ sw)];
+          split3(f32x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w}, ah[mi], am[mi], al[mi]);
+        }
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+          const int r = wn * WTN + ni * 32 + lr, sw = (r >> 1) & 7;
+          const float4 lo = Bs[r * 8 + (c0 ^ sw)], hi = Bs[r * 8 + ((c0 + 1) ^ sw)];
+          split3(f32x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w}, bh[ni], bm2[ni], bl[ni]);
+        }
+        // piece pairs outermost (small terms first): consecutive MFMAs go to different accumulators
+#pragma unroll
+        for (int pp = 0; pp < 6; ++pp)
+#pragma unroll
+          for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+              const bf16x8_t a = pp == 0 ? al[mi] : (pp == 2 || pp == 3) ? am[mi] : ah[mi];
+              const bf16x8_t b = pp == 1 ? bl[ni] : (pp == 2 || pp == 4) ? bm2[ni] : bh[ni];
+              // the five small piece pairs have their own accumulator (2^-8 of the main one): their
+              // rounding happens at 2^-32 of the result, and the main accumulator sees one add per k16
+              if (pp < 5) acc2[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc2[mi][ni], 0, 0, 0);
+              else acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[mi][ni], 0, 0, 0);
+              const int g = ((s2 * 6 + pp) * TM + mi) * TN + ni;     // 0 .. 12*TM*TN-1
+#pragma unroll
+              for (int q = 0; q < ND; ++q)
+                if (q * (12 * TM * TN) / ND + 1 == g) issue_one(q);
+            }
+      }
+    } else if constexpr (PREC == FCD_PREC_BF16) {
       // bf16 MFMA on the same fp32 LDS image: lane half h of k16-step s owns k = 16s + 8h .. +7
       // (two 16-byte chunks), rounded to bf16 in registers (v_cvt_pk_bf16_f32)
 #pragma unroll
@@ -444,6 +523,14 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
     issue_advance();
     stage = stage + 1 == S ? 0 : stage + 1;
     nstage = nstage + 1 == S ? 0 : nstage + 1;
+  }
+  if constexpr (PREC == FCD_PREC_BF16X3) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] += acc2[i][j][r];
   }
   __syncthreads();   // rowoff visible even when nk == 0
 
@@ -570,10 +657,10 @@ __device__ __forceinline__ void read_vec(const float* p, float* out) {
 // DMA instruction of a wave writes 1 KiB = 256/BM consecutive pixel rows).
 // M16: at most 16 output channels (v_mfma_f32_16x16x4_f32 tiles; the A stage keeps its 32-column
 // LDS slot, only columns 0..15 are read).
-template <int BM, int BN, int WM, int WN, int S, bool BF16, bool M16 = false>
+template <int BM, int BN, int WM, int WN, int S, int PREC, bool M16 = false>
 __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_dma_kernel(const WgradArgs p, const unsigned gs_bytes,
                                                                       const unsigned xb_bytes) {
-  static_assert(!M16 || (BM == 32 && WM == 1 && !BF16), "M16 shape");
+  static_assert(!M16 || (BM == 32 && WM == 1 && PREC == FCD_PREC_F32), "M16 shape");
   constexpr int NW = WM * WN;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
@@ -667,6 +754,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_dma_kernel(const Wgra
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  f32x16 acc2[PREC == FCD_PREC_BF16X3 ? TM : 1][PREC == FCD_PREC_BF16X3 ? TN : 1];   // small terms (BF16X3)
+  if constexpr (PREC == FCD_PREC_BF16X3) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[i][j][r] = 0.f;
+  }
 
   f32x4 acc16[WTN / 16];
 #pragma unroll
@@ -710,7 +806,41 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_dma_kernel(const Wgra
         for (int q = 0; q < ND; ++q)
           if (q * 8 / ND == kk) issue_one(q);
       }
-    } else if constexpr (BF16) {
+    } else if constexpr (PREC == FCD_PREC_BF16X3) {
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        bf16x8_t ah[TM], am[TM], al[TM], bh[TN], bm2[TN], bl[TN];
+        const int k0 = 16 * s2 + 8 * lh;
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+          const float* c = As + k0 * BM + wm * WTM + TM * lr + mi;
+          split3(f32x8{c[0], c[BM], c[2 * BM], c[3 * BM], c[4 * BM], c[5 * BM], c[6 * BM], c[7 * BM]}, ah[mi], am[mi], al[mi]);
+        }
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+          const float* c = Bs + k0 * BN + wn * WTN + TN * lr + ni;
+          split3(f32x8{c[0], c[BN], c[2 * BN], c[3 * BN], c[4 * BN], c[5 * BN], c[6 * BN], c[7 * BN]}, bh[ni], bm2[ni], bl[ni]);
+        }
+        // piece pairs outermost (small terms first): consecutive MFMAs go to different accumulators
+#pragma unroll
+        for (int pp = 0; pp < 6; ++pp)
+#pragma unroll
+          for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+              const bf16x8_t a = pp == 0 ? al[mi] : (pp == 2 || pp == 3) ? am[mi] : ah[mi];
+              const bf16x8_t b = pp == 1 ? bl[ni] : (pp == 2 || pp == 4) ? bm2[ni] : bh[ni];
+              // the five small piece pairs have their own accumulator (2^-8 of the main one): their
+              // rounding happens at 2^-32 of the result, and the main accumulator sees one add per k16
+              if (pp < 5) acc2[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc2[mi][ni], 0, 0, 0);
+              else acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[mi][ni], 0, 0, 0);
+              const int g = ((s2 * 6 + pp) * TM + mi) * TN + ni;     // 0 .. 12*TM*TN-1
+#pragma unroll
+              for (int q = 0; q < ND; ++q)
+                if (q * (12 * TM * TN) / ND + 1 == g) issue_one(q);
+            }
+      }
+    } else if constexpr (PREC == FCD_PREC_BF16) {
       // k = pixel: lane half h of k16-step s owns pixels 16s + 8h .. +7 of its column
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
@@ -769,6 +899,14 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_dma_kernel(const Wgra
     nstage = nstage + 1 == S ? 0 : nstage + 1;
   }
 
+  if constexpr (PREC == FCD_PREC_BF16X3) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] += acc2[i][j][r];
+  }
   float* __restrict__ dst = p.slab + (long)ks * p.O * p.ND;
   if constexpr (M16) {
     // D[o = 4*(lane>>4) + r][col = lane&15]
@@ -853,9 +991,11 @@ int launch_gather(const GatherArgs& a, int precision, hipStream_t st) {
   const unsigned in_bytes = (unsigned)((size_t)a.N * a.IH * a.IW * a.Cin * 4);
   const unsigned w_bytes = (unsigned)((size_t)a.Cout * a.K * 4);
   if (precision == FCD_PREC_BF16)
-    hipLaunchKernelGGL((conv_gather_dma_kernel<BM, BN, WM, WN, 3, true>), grid, dim3(64 * WM * WN), 0, st, a, in_bytes, w_bytes);
+    hipLaunchKernelGGL((conv_gather_dma_kernel<BM, BN, WM, WN, 3, FCD_PREC_BF16>), grid, dim3(64 * WM * WN), 0, st, a, in_bytes, w_bytes);
+  else if (precision == FCD_PREC_BF16X3)
+    hipLaunchKernelGGL((conv_gather_dma_kernel<BM, BN, WM, WN, 3, FCD_PREC_BF16X3>), grid, dim3(64 * WM * WN), 0, st, a, in_bytes, w_bytes);
   else
-    hipLaunchKernelGGL((conv_gather_dma_kernel<BM, BN, WM, WN, 3, false>), grid, dim3(64 * WM * WN), 0, st, a, in_bytes, w_bytes);
+    hipLaunchKernelGGL((conv_gather_dma_kernel<BM, BN, WM, WN, 3, FCD_PREC_F32>), grid, dim3(64 * WM * WN), 0, st, a, in_bytes, w_bytes);
   return fcd_check_launch("conv_gather");
 }
 
@@ -865,9 +1005,11 @@ int launch_wgrad(const WgradArgs& a, int precision, hipStream_t st) {
   const unsigned gs_bytes = (unsigned)((size_t)a.P * a.OP * 4);
   const unsigned xb_bytes = (unsigned)((size_t)a.N * a.BH * a.BW * a.IP * 4);
   if (precision == FCD_PREC_BF16)
-    hipLaunchKernelGGL((conv_wgrad_dma_kernel<BM, BN, WM, WN, 3, true>), grid, dim3(64 * WM * WN), 0, st, a, gs_bytes, xb_bytes);
+    hipLaunchKernelGGL((conv_wgrad_dma_kernel<BM, BN, WM, WN, 3, FCD_PREC_BF16>), grid, dim3(64 * WM * WN), 0, st, a, gs_bytes, xb_bytes);
+  else if (precision == FCD_PREC_BF16X3)
+    hipLaunchKernelGGL((conv_wgrad_dma_kernel<BM, BN, WM, WN, 3, FCD_PREC_BF16X3>), grid, dim3(64 * WM * WN), 0, st, a, gs_bytes, xb_bytes);
   else
-    hipLaunchKernelGGL((conv_wgrad_dma_kernel<BM, BN, WM, WN, 3, false>), grid, dim3(64 * WM * WN), 0, st, a, gs_bytes, xb_bytes);
+    hipLaunchKernelGGL((conv_wgrad_dma_kernel<BM, BN, WM, WN, 3, FCD_PREC_F32>), grid, dim3(64 * WM * WN), 0, st, a, gs_bytes, xb_bytes);
   return fcd_check_launch("conv_wgrad");
 }
 
@@ -881,7 +1023,8 @@ int validate_conv(const FcdConvDesc* d) {
   FCD_REQUIRE(d->istride >= 1 && d->ostride >= 1, "conv: strides");
   FCD_REQUIRE(d->nphase >= 1 && d->nphase <= 4, "conv: nphase=%d", d->nphase);
   FCD_REQUIRE(d->splitk >= 0 && d->splitk <= 1024, "conv: splitk=%d", d->splitk);
-  FCD_REQUIRE(d->precision == FCD_PREC_F32 || d->precision == FCD_PREC_BF16, "conv: precision");
+  FCD_REQUIRE(d->precision == FCD_PREC_F32 || d->precision == FCD_PREC_BF16 || d->precision == FCD_PREC_BF16X3,
+              "conv: precision");
   for (int ph = 0; ph < d->nphase; ++ph) {
     const long oh = (long)(d->GH - 1) * d->ostride + d->ooff_h[ph];
     const long ow = (long)(d->GW - 1) * d->ostride + d->ooff_w[ph];
@@ -898,7 +1041,8 @@ int validate_conv(const FcdConvDesc* d) {
 // tile shape by problem shape (shared by the workspace query and the launch)
 void gather_tile(const FcdConvDesc* d, int& bm, int& bn) {
   const long M = (long)d->N * d->GH * d->GW;
-  if (d->Cout <= 16 && d->precision == FCD_PREC_F32) { bm = 128; bn = 16; }   // 16-wide MFMA tiles
+  // 16-wide MFMA tiles (exact fp32; also serves FCD_PREC_BF16X3, whose contract is fp32-faithful results)
+  if (d->Cout <= 16 && d->precision != FCD_PREC_BF16) { bm = 128; bn = 16; }
   else if (d->Cout <= 32) { bm = 128; bn = 32; }
   else if (d->Cout <= 64) { bm = 128; bn = 64; }
   else if (M <= 64) { bm = 64; bn = 128; }
@@ -966,9 +1110,9 @@ int run_gather(const FcdConvDesc* d, GatherArgs& a, hipStream_t st) {
   gather_tile(d, bm, bn);
   a.tiles_m = fcd_cdiv(a.M, bm);
   a.tiles_n = fcd_cdiv(d->Cout, bn);
-  if (bm == 128 && bn == 16 && d->precision == FCD_PREC_F32) {
+  if (bm == 128 && bn == 16 && d->precision != FCD_PREC_BF16) {
     dim3 grid(a.tiles_m * a.tiles_n, a.nphase * a.splitk);
-    hipLaunchKernelGGL((conv_gather_dma_kernel<128, 32, 4, 1, 3, false, true>), grid, dim3(256), 0, st, a,
+    hipLaunchKernelGGL((conv_gather_dma_kernel<128, 32, 4, 1, 3, FCD_PREC_F32, true>), grid, dim3(256), 0, st, a,
                        (unsigned)((size_t)a.N * a.IH * a.IW * a.Cin * 4), (unsigned)((size_t)a.Cout * a.K * 4));
     rc = fcd_check_launch("conv_gather");
   } else if (bm == 128 && bn == 32) rc = launch_gather<128, 32, 4, 1>(a, d->precision, st);
@@ -1075,7 +1219,7 @@ static int resolve_wgrad_splitk(const FcdWgradDesc* d) {
   // aim at one workgroup per CU (the DMA ring keeps a lone workgroup's MFMA pipes fed); more
   // splits only add slab traffic
   // (the 16-row kernel is short of MFMA work per tile: two workgroups per CU hide its DMA latency)
-  const long want = (d->O <= 16 && d->precision == FCD_PREC_F32) ? 512 : 256;
+  const long want = (d->O <= 16 && d->precision != FCD_PREC_BF16) ? 512 : 256;
   long sk = (want + tiles / 2) / tiles;
   if (sk > ktiles / 8) sk = ktiles / 8;
   if (sk > 512) sk = 512;
@@ -1124,10 +1268,10 @@ extern "C" int fcd_conv_wgrad(const FcdWgradDesc* d, const float* gsmall, const 
   a.splitk = fcd_cdiv(a.ktiles, a.ktiles_per_split);
   a.accumulate = d->accumulate;
   hipStream_t st = fcd_stream(stream);
-  if (d->O <= 16 && d->precision == FCD_PREC_F32) {
+  if (d->O <= 16 && d->precision != FCD_PREC_BF16) {   // exact fp32 16-row kernel, also under BF16X3
     a.tiles_m = 1; a.tiles_n = fcd_cdiv(a.ND, 128);
     dim3 grid(a.tiles_n, a.splitk);
-    hipLaunchKernelGGL((conv_wgrad_dma_kernel<32, 128, 1, 4, 3, false, true>), grid, dim3(256), 0, st, a,
+    hipLaunchKernelGGL((conv_wgrad_dma_kernel<32, 128, 1, 4, 3, FCD_PREC_F32, true>), grid, dim3(256), 0, st, a,
                        (unsigned)((size_t)a.P * a.OP * 4), (unsigned)((size_t)a.N * a.BH * a.BW * a.IP * 4));
     rc = fcd_check_launch("conv_wgrad");
   } else if (d->O <= 32) {

@@ -71,6 +71,7 @@ class Discriminator(nn.Module):
             raise NotImplementedError("D needs an activation with positive slope (masks come from the output sign)")
         self.image_size, self.c_dim, self.num_channels = image_size, c_dim, num_channels
         self.precision = L.PREC_F32
+        self.wgrad_precision = None          # None: same as precision
         layers = []
         geoms = []
         cin, cout = num_channels, conv_dim
@@ -150,6 +151,7 @@ class _DBackwardFn(torch.autograd.Function):
     def forward(ctx, mod: Discriminator, acts, prec, want_x, want_params, g_src, g_cls, g_feat, *params):
         n = acts[0].shape[0]
         slope = mod.slope
+        prec_w = prec if mod.wgrad_precision is None else mod.wgrad_precision
         top = acts[-1]
         nl = len(mod._convs)
         dev = top.device
@@ -190,7 +192,7 @@ class _DBackwardFn(torch.autograd.Function):
             if want_params:
                 cv = mod._convs[li]
                 sink = grad_sink(cv.weight, True)
-                wd = g.wgrad_desc(n, a_in.shape[1], a_in.shape[2], precision=prec, accumulate=sink is not None)
+                wd = g.wgrad_desc(n, a_in.shape[1], a_in.shape[2], precision=prec_w, accumulate=sink is not None)
                 dw = ops.conv_wgrad(wd, gz, a_in, dw=sink)
                 grads[2 * li] = None if sink is not None else dw
                 bsink = grad_sink(cv.bias, gz.shape[3] == g.O)
@@ -218,6 +220,7 @@ class _DBackwardFn(torch.autograd.Function):
         if any(t is not None for t in gg_params):
             raise NotImplementedError("differentiating through D's parameter gradients is not supported")
         mod, acts, prec, gzs = ctx.mod, ctx.acts, ctx.prec, ctx.gzs
+        prec_w = prec if mod.wgrad_precision is None else mod.wgrad_precision
         nl = len(mod._convs)
         # inputs: mod, acts, prec, want_x, want_params, g_src, g_cls, g_feat, *params
         needs = ctx.needs_input_grad[8:]
@@ -231,7 +234,7 @@ class _DBackwardFn(torch.autograd.Function):
             g = mod._geoms[li]
             if needs[2 * li]:
                 sink = grad_sink(mod._convs[li].weight, True)
-                wd = g.wgrad_desc(n, u.shape[1], u.shape[2], precision=prec, accumulate=sink is not None)
+                wd = g.wgrad_desc(n, u.shape[1], u.shape[2], precision=prec_w, accumulate=sink is not None)
                 dw = ops.conv_wgrad(wd, gzs[li], u, dw=sink)
                 out[2 * li] = None if sink is not None else dw
             if needs[2 * li + 1] and grad_sink(mod._convs[li].bias, True) is None:

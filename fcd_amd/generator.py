@@ -118,6 +118,7 @@ class Generator(nn.Module):
         self.conv_dim, self.c_dim, self.repeat_num = conv_dim, c_dim, repeat_num
         self.num_channels, self.activation = num_channels, activation
         self.precision = L.PREC_F32
+        self.wgrad_precision = None          # None: same as precision
         cin = num_channels + c_dim
         mods: List[nn.Module] = []
         plan: List[_Layer] = []
@@ -229,6 +230,7 @@ class _GeneratorFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout):
         mod, acts, saved, x, x_fake, prec = ctx.mod, ctx.acts, ctx.saved_layers, ctx.x, ctx.x_fake, ctx.prec
+        prec_w = prec if mod.wgrad_precision is None else mod.wgrad_precision
         plan = mod._plan
         n = x.shape[0]
         need_x = ctx.needs_input_grad[1]
@@ -276,10 +278,10 @@ class _GeneratorFn(torch.autograd.Function):
             if needs[p0]:
                 sink = grad_sink(ly.conv.weight, True)     # arena-backed: accumulate into p.grad in place
                 if ly.kind == "conv":
-                    wd = gm.wgrad_desc(n, a_in.shape[1], a_in.shape[2], precision=prec, accumulate=sink is not None)
+                    wd = gm.wgrad_desc(n, a_in.shape[1], a_in.shape[2], precision=prec_w, accumulate=sink is not None)
                     dw = ops.conv_wgrad(wd, dz, a_in, dw=sink)
                 else:
-                    wd = gm.wgrad_desc(n, dz.shape[1], dz.shape[2], precision=prec, accumulate=sink is not None)
+                    wd = gm.wgrad_desc(n, dz.shape[1], dz.shape[2], precision=prec_w, accumulate=sink is not None)
                     dw = ops.conv_wgrad(wd, a_in, dz, dw=sink)
                 if sink is None:
                     grads[p0] = dw

@@ -40,6 +40,8 @@ extern "C" {
 /* precision of the MFMA contraction */
 #define FCD_PREC_F32 0   /* v_mfma_f32_32x32x2_f32: exact fp32 fma chain     */
 #define FCD_PREC_BF16 1  /* operands rounded to bf16 at LDS staging, fp32 accumulate */
+#define FCD_PREC_BF16X3 2 /* each fp32 operand split into three bf16 pieces in registers, six bf16 MFMAs
+                             per product group, fp32 accumulate: fp32-faithful at the bf16 matrix rate */
 
 const char* fcd_last_error(void);
 int fcd_abi_version(void);

@@ -28,8 +28,8 @@ def full(dev):
     ds = O.synth_discriminator_state(cfg["size"], cfg["d_conv_dim"], cfg["c_dim"], cfg["d_repeat"], cfg["bands"])
     batch, alpha = O.synth_batch(cfg["batch"], cfg["size"], cfg["bands"])
 
-    def make():
-        s = FCDSolver(None)
+    def make(precision="fp32"):
+        s = FCDSolver(None, precision=precision)
         s.G.load_state_dict(gs)
         s.D.load_state_dict(ds)
         return s.to(dev)
@@ -49,9 +49,11 @@ def sample_errors(grad, tag, name):
     return float((got - o64).norm()) / den, float((r32 - o64).norm()) / den
 
 
-def test_full_d_step(full):
+# fp32x3: weight gradients on the bf16 pipe with 3-way split operands (same bars as exact fp32)
+@pytest.mark.parametrize("prec", ["fp32", "fp32x3"])
+def test_full_d_step(full, prec):
     sc, make, b, alpha = full
-    s = make()
+    s = make(prec)
     s.alpha_override = alpha
     s.G.requires_grad_(False)
     loss = s.training_step(b, 0, 0)
@@ -66,12 +68,13 @@ def test_full_d_step(full):
         assert e <= bar, (name, e, eref)
         n64 = sc["d_grad_norm64"][name]
         assert abs(float(p.grad.double().norm()) - n64) <= bar * n64, name
-    print("full D-step: worst error / bar =", worst)
+    print("full D-step", prec, ": worst error / bar =", worst)
 
 
-def test_full_g_step(full):
+@pytest.mark.parametrize("prec", ["fp32", "fp32x3"])
+def test_full_g_step(full, prec):
     sc, make, b, alpha = full
-    s = make()
+    s = make(prec)
     s.D.requires_grad_(False)
     s.global_step = s.n_critic - 1
     loss = s.training_step(b, 0, 1)
@@ -84,7 +87,7 @@ def test_full_g_step(full):
         bar = max(1e-4, 2 * eref)
         worst = max(worst, e / bar)
         assert e <= bar, (name, e, eref)
-    print("full G-step: worst error / bar =", worst)
+    print("full G-step", prec, ": worst error / bar =", worst)
 
 
 def test_full_masks_and_eval_forward(full):

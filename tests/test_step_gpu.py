@@ -77,9 +77,11 @@ def test_discriminator_forward(dev, tiny):
     assert relerr(feat[0], torch.from_numpy(z["D_feat"])) <= TOL
 
 
-def test_d_step_losses_and_grads(dev, tiny):
+@pytest.mark.parametrize("prec", ["fp32", "fp32x3"])
+def test_d_step_losses_and_grads(dev, tiny, prec):
     z, sc = tiny
     s = build(z, sc["cfg"], dev)
+    s.set_precision(prec)
     b = batch_of(z, dev)
     s.alpha_override = torch.from_numpy(z["alpha"])
     s.G.requires_grad_(False)
@@ -103,9 +105,11 @@ def test_d_step_losses_and_grads(dev, tiny):
     print("D-step worst grad rel-err", worst)
 
 
-def test_g_step_losses_and_grads(dev, tiny):
+@pytest.mark.parametrize("prec", ["fp32", "fp32x3"])
+def test_g_step_losses_and_grads(dev, tiny, prec):
     z, sc = tiny
     s = build(z, sc["cfg"], dev)
+    s.set_precision(prec)
     b = batch_of(z, dev)
     s.D.requires_grad_(False)
     s.global_step = s.n_critic - 1
