@@ -43,9 +43,9 @@ def dominant_kernel_roofline(precision, dev, in_step_us=None, in_step_launches=0
     n, h, w = BASE["batch"], 32, 32
     x = torch.randn(n, h, w, 256, device=dev)
     wt = torch.randn(256, 256, 3, 3, device=dev) / 48.0
-    wf = ops.pack_weight_fwd(wt, g)
     prec = {"fp32": L.PREC_F32, "fp32x3": L.PREC_BF16X3, "bf16": L.PREC_BF16}[precision]
     d = g.fwd_desc(n, h, w, precision=prec)
+    wf = ops.pack_weight_fwd_x3(wt, g) if ops.wants_split_weights(d) else ops.pack_weight_fwd(wt, g)
     out = ops.conv_gather(d, x, wf)
     for _ in range(3):
         ops.conv_gather(d, x, wf, out=out)

@@ -64,6 +64,9 @@ PROTOTYPES = {
     "fcd_conv_wgrad": (_I, [C.POINTER(WgradDesc), _P, _P, _P, _P, _Z, _P]),
     "fcd_pack_weight_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "fcd_pack_weight_adj": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "fcd_conv_wants_split_weights": (_I, [C.POINTER(ConvDesc)]),
+    "fcd_pack_weight_fwd_x3": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "fcd_pack_weight_adj_x3": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "fcd_head_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "fcd_head_dgrad": (_I, [_P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "fcd_head_wgrad": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),

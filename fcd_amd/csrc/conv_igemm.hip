@@ -216,7 +216,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 
 // N16: the output-channel tile is 16 wide (v_mfma_f32_16x16x4_f32) for the 10/12-channel image
 // layers; the B stage keeps its 32-row LDS slot, rows 16.. are loaded as zeros and never read.
-template <int BM, int BN, int WM, int WN, int S, int PREC, bool N16 = false>
+// BPRE (FCD_PREC_BF16X3 only): the weights arrive already split into three bf16 planes
+// ([plane][row][K], fcd_pack_weight_*_x3), so only the activation fragments are split in registers.
+template <int BM, int BN, int WM, int WN, int S, int PREC, bool N16 = false, bool BPRE = false>
 __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const GatherArgs p, const unsigned in_bytes,
                                                                        const unsigned w_bytes) {
   static_assert(!N16 || (BN == 32 && WN == 1 && PREC == FCD_PREC_F32), "N16 shape");
@@ -225,8 +227,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
   constexpr int RPI = 8 * NW;                   // tile rows one DMA instruction of every wave covers
-  constexpr int AL = BM / RPI, BL = BN / RPI;   // DMA instructions per wave per K-tile
-  constexpr int STAGE = (BM + BN) * 8;          // float4 chunks per stage
+  static_assert(!BPRE || (PREC == FCD_PREC_BF16X3 && BN % (2 * NW) == 0 && !N16), "BPRE shape");
+  // BPRE: a B row is 3 planes x 4 chunks (32 bf16 each); one DMA instruction covers 16 rows of a plane
+  constexpr int BROWCH = BPRE ? 12 : 8;         // float4 chunks per B row
+  constexpr int AL = BM / RPI, BL = BPRE ? 3 * BN / (16 * NW) : BN / RPI;   // DMA instructions per wave per K-tile
+  constexpr int STAGE = BM * 8 + BN * BROWCH;   // float4 chunks per stage
   static_assert((NW == 4 || NW == 8) && S >= 2 && BM % RPI == 0 && BN % RPI == 0 && TM >= 1 && TN >= 1, "shape");
 
   __shared__ float4 smem[S * STAGE + BM / 2];   // ring + rowoff (BM longs)
@@ -279,10 +284,21 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
     }
   }
   unsigned b_base[BL];
+  if constexpr (BPRE) {
+    // instruction ii = wave + NW*i of the tile: plane = ii / (BN/16), rows 16*(ii % (BN/16)) + (lane>>2),
+    // slot lane&3 holds chunk slot ^ ((row>>2)&3) (8 bf16 = 16 bytes per chunk)
 #pragma unroll
-  for (int i = 0; i < BL; ++i) {
-    const int co = tn * BNC + rl + RPI * i;
-    b_base[i] = (co < p.Cout && rl + RPI * i < BNC) ? (unsigned)(co * p.K * 4) : OOB;
+    for (int i = 0; i < BL; ++i) {
+      const int ii = wave + NW * i, plane = ii / (BN / 16), row = 16 * (ii % (BN / 16)) + (lane >> 2);
+      const int co = tn * BN + row, chunk = (lane & 3) ^ ((row >> 2) & 3);
+      b_base[i] = co < p.Cout ? (unsigned)((((long)plane * p.Cout + co) * p.K + chunk * 8) * 2) : OOB;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < BL; ++i) {
+      const int co = tn * BNC + rl + RPI * i;
+      b_base[i] = (co < p.Cout && rl + RPI * i < BNC) ? (unsigned)(co * p.K * 4) : OOB;
+    }
   }
 
   const int kt0 = ks * p.ktiles_per_split;
@@ -312,7 +328,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
   // end of this block's K range are issued as all-out-of-range dummies (zeros into a free stage).
   constexpr int ND = AL + BL;
   unsigned tapoff = 0, thc = 0, live = 0, la = 0, lb = 0;
+  int bstage = 0;
   auto issue_prepare = [&](int stage, bool alive) {
+    bstage = stage;
     tapoff = (unsigned)(((th * p.IW + tw) * p.Cin + ci) * 4);
     thc = th < 31 ? th : 31;
     live = alive ? 0xFFFFFFFFu : 0u;
@@ -325,8 +343,14 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
       const unsigned voff = (((unsigned)a_base[q] + tapoff) & okm) | (OOB & ~okm);
       dma16(rin, voff, la + q * (RPI * 8 * 16));
     } else {
-      const unsigned voff = (b_base[q - AL] + (unsigned)(k * 4)) | (OOB & ~live);   // invalid rows stay >= OOB
-      dma16(rw, voff, lb + (q - AL) * (RPI * 8 * 16));
+      if constexpr (BPRE) {
+        // tile-level k (this lane's k minus its own A chunk), 2 bytes per element
+        const unsigned voff = (b_base[q - AL] + (unsigned)((k - kc * 4) * 2)) | (OOB & ~live);
+        dma16(rw, voff, lds0 + (unsigned)(bstage * STAGE + BM * 8) * 16u + (unsigned)((wave + NW * (q - AL)) * 1024));
+      } else {
+        const unsigned voff = (b_base[q - AL] + (unsigned)(k * 4)) | (OOB & ~live);   // invalid rows stay >= OOB
+        dma16(rw, voff, lb + (q - AL) * (RPI * 8 * 16));
+      }
     }
   };
   auto issue_advance = [&]() {
@@ -426,9 +450,16 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
         }
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni) {
-          const int r = wn * WTN + ni * 32 + lr, sw = (r >> 1) & 7;
-          const float4 lo = Bs[r * 8 + (c0 ^ sw)], hi = Bs[r * 8 + ((c0 + 1) ^ sw)];
-          split3(f32x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w}, bh[ni], bm2[ni], bl[ni]);
+          if constexpr (BPRE) {
+            const int r = wn * WTN + ni * 32 + lr, c = (2 * s2 + lh) ^ ((r >> 2) & 3);
+            bh[ni] = __builtin_bit_cast(bf16x8_t, Bs[(0 * BN + r) * 4 + c]);
+            bm2[ni] = __builtin_bit_cast(bf16x8_t, Bs[(1 * BN + r) * 4 + c]);
+            bl[ni] = __builtin_bit_cast(bf16x8_t, Bs[(2 * BN + r) * 4 + c]);
+          } else {
+            const int r = wn * WTN + ni * 32 + lr, sw = (r >> 1) & 7;
+            const float4 lo = Bs[r * 8 + (c0 ^ sw)], hi = Bs[r * 8 + ((c0 + 1) ^ sw)];
+            split3(f32x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w}, bh[ni], bm2[ni], bl[ni]);
+          }
         }
         // piece pairs outermost (small terms first): consecutive MFMAs go to different accumulators
 #pragma unroll
@@ -985,6 +1016,61 @@ __global__ __launch_bounds__(256) void pack_adj_kernel(const float* __restrict__
   }
 }
 
+// fp32 -> (h, m, l) bf16 bit patterns, round to nearest even at each level (host-side twin of split3)
+__device__ __forceinline__ unsigned short bf16_rn(float v) {
+  const unsigned u = __float_as_uint(v);
+  return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+__device__ __forceinline__ void store_split3(unsigned short* __restrict__ out, long plane_stride, long idx, float v) {
+  const unsigned short h = bf16_rn(v);
+  const float r1 = v - __uint_as_float((unsigned)h << 16);
+  const unsigned short m = bf16_rn(r1);
+  const float r2 = r1 - __uint_as_float((unsigned)m << 16);
+  out[idx] = h;
+  out[plane_stride + idx] = m;
+  out[2 * plane_stride + idx] = bf16_rn(r2);
+}
+
+// out[plane][o][tap][ip] bf16
+__global__ __launch_bounds__(256) void pack_fwd_x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ out,
+                                                          int O, int I, int IP, int taps) {
+  const long total = (long)O * taps * IP;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int i = (int)(idx % IP);
+    const long t2 = idx / IP;
+    const int tap = (int)(t2 % taps), o = (int)(t2 / taps);
+    store_split3(out, total, idx, i < I ? w[((long)o * I + i) * taps + tap] : 0.f);
+  }
+}
+
+// out[phase][plane][i][th][tw][o] bf16
+__global__ __launch_bounds__(256) void pack_adj_x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ out,
+                                                          int O, int OP, int I, int KH, int KW, int stride) {
+  const int TH = stride == 1 ? KH : 2, TW = stride == 1 ? KW : 2;
+  const int nph = stride == 1 ? 1 : 4;
+  const long per_phase = (long)I * TH * TW * OP;
+  const long total = (long)nph * per_phase;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int o = (int)(idx % OP);
+    long t = idx / OP;
+    const int tw = (int)(t % TW); t /= TW;
+    const int th = (int)(t % TH); t /= TH;
+    const int i = (int)(t % I);
+    const int ph = (int)(t / I);
+    int kh, kw;
+    if (stride == 1) {
+      kh = KH - 1 - th;
+      kw = KW - 1 - tw;
+    } else {
+      const int py = ph >> 1, px = ph & 1;
+      kh = 3 - py - 2 * th;
+      kw = 3 - px - 2 * tw;
+    }
+    const float v = o < O ? w[(((long)o * I + i) * KH + kh) * KW + kw] : 0.f;
+    store_split3(out + (long)ph * 3 * per_phase, per_phase, idx - (long)ph * per_phase, v);
+  }
+}
+
 template <int BM, int BN, int WM, int WN>
 int launch_gather(const GatherArgs& a, int precision, hipStream_t st) {
   dim3 grid(a.tiles_m * a.tiles_n, a.nphase * a.splitk);
@@ -1105,9 +1191,34 @@ int gather_wave_rows(int bm, int bn) {
   return 32;
 }
 
+// FCD_PREC_BF16X3 with 128x128 tiles and 32-channel K slices: the kernel takes pre-split weights
+bool wants_split_weights(const FcdConvDesc* d) {
+  if (d->precision != FCD_PREC_BF16X3 || d->Cin % 32 != 0) return false;
+  int bm, bn;
+  gather_tile(d, bm, bn);
+  return bm == 128 && bn == 128;
+}
+
 int run_gather(const FcdConvDesc* d, GatherArgs& a, hipStream_t st) {
   int bm, bn, rc;
   gather_tile(d, bm, bn);
+  if (wants_split_weights(d)) {
+    a.tiles_m = fcd_cdiv(a.M, 128);
+    a.tiles_n = fcd_cdiv(d->Cout, 128);
+    a.w_phase_stride = (long)d->Cout * a.K * 3 / 2;      // three bf16 planes, in units of 4 bytes
+    dim3 grid(a.tiles_m * a.tiles_n, a.nphase * a.splitk);
+    hipLaunchKernelGGL((conv_gather_dma_kernel<128, 128, 2, 4, 3, FCD_PREC_BF16X3, false, true>), grid, dim3(512), 0, st, a,
+                       (unsigned)((size_t)a.N * a.IH * a.IW * a.Cin * 4), (unsigned)((size_t)a.Cout * a.K * 6));
+    rc = fcd_check_launch("conv_gather");
+    if (rc) return rc;
+    if (a.splitk > 1) {
+      const long total = (long)a.nphase * a.M * a.CoutP;
+      const int blocks = (int)std::min<long>(fcd_cdiv(total, 256), 4096);
+      hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, a);
+      rc = fcd_check_launch("conv_splitk_reduce");
+    }
+    return rc;
+  }
   a.tiles_m = fcd_cdiv(a.M, bm);
   a.tiles_n = fcd_cdiv(d->Cout, bn);
   if (bm == 128 && bn == 16 && d->precision != FCD_PREC_BF16) {
@@ -1300,6 +1411,31 @@ extern "C" int fcd_pack_weight_fwd(const float* w, float* packed, int O, int I, 
   const int blocks = (int)std::min<long>(fcd_cdiv(total, 256), 4096);
   hipLaunchKernelGGL(pack_fwd_kernel, dim3(blocks), dim3(256), 0, fcd_stream(stream), w, packed, O, I, IP, KH * KW);
   return fcd_check_launch("pack_fwd");
+}
+
+extern "C" int fcd_conv_wants_split_weights(const FcdConvDesc* d) {
+  return (d && validate_conv(d) == FCD_OK && wants_split_weights(d)) ? 1 : 0;
+}
+
+extern "C" int fcd_pack_weight_fwd_x3(const float* w, void* packed, int O, int I, int IP, int KH, int KW, void* stream) {
+  FCD_REQUIRE(w && packed && O > 0 && I > 0 && IP >= I && IP % 4 == 0 && KH > 0 && KW > 0, "pack_weight_fwd_x3: bad arguments");
+  const long total = (long)O * KH * KW * IP;
+  const int blocks = (int)std::min<long>(fcd_cdiv(total, 256), 4096);
+  hipLaunchKernelGGL(pack_fwd_x3_kernel, dim3(blocks), dim3(256), 0, fcd_stream(stream), w, (unsigned short*)packed, O, I,
+                     IP, KH * KW);
+  return fcd_check_launch("pack_weight_fwd_x3");
+}
+
+extern "C" int fcd_pack_weight_adj_x3(const float* w, void* packed, int O, int OP, int I, int KH, int KW, int stride,
+                                      void* stream) {
+  FCD_REQUIRE(w && packed && O > 0 && I > 0 && OP >= O && OP % 4 == 0, "pack_weight_adj_x3: bad arguments");
+  FCD_REQUIRE((stride == 1) || (stride == 2 && KH == 4 && KW == 4), "pack_weight_adj_x3: unsupported stride/kernel");
+  const int TH = stride == 1 ? KH : 2, TW = stride == 1 ? KW : 2, nph = stride == 1 ? 1 : 4;
+  const long total = (long)nph * I * TH * TW * OP;
+  const int blocks = (int)std::min<long>(fcd_cdiv(total, 256), 4096);
+  hipLaunchKernelGGL(pack_adj_x3_kernel, dim3(blocks), dim3(256), 0, fcd_stream(stream), w, (unsigned short*)packed, O, OP,
+                     I, KH, KW, stride);
+  return fcd_check_launch("pack_weight_adj_x3");
 }
 
 extern "C" int fcd_pack_weight_adj(const float* w, float* packed, int O, int OP, int I, int KH, int KW,

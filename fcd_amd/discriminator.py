@@ -117,7 +117,7 @@ class _DiscriminatorFn(torch.autograd.Function):
         for li, (cv, g) in enumerate(zip(mod._convs, mod._geoms)):
             a = acts[-1]
             d = g.fwd_desc(n, a.shape[1], a.shape[2], precision=prec, act_slope=mod.slope)
-            acts.append(ops.conv_gather(d, a, cv.packed("fwd", g), bias=params[2 * li + 1]))
+            acts.append(ops.conv_gather(d, a, cv.operand("fwd", g, d), bias=params[2 * li + 1]))
         top = acts[-1]
         if top.shape[1] < mod._g2.k or top.shape[2] < mod._g2.k:
             raise RuntimeError("Discriminator: input smaller than image_size")
@@ -202,11 +202,11 @@ class _DBackwardFn(torch.autograd.Function):
             if li == 0:
                 if want_x:
                     d = g.adj_desc(n, gz.shape[1], gz.shape[2], precision=prec)
-                    g0 = ops.conv_gather(d, gz, mod._convs[0].packed("adj", g))
+                    g0 = ops.conv_gather(d, gz, mod._convs[0].operand("adj", g, d))
                     gx = ops.nhwc_to_nchw(g0, mod.num_channels)
                 break
             d = g.adj_desc(n, gz.shape[1], gz.shape[2], precision=prec, mask_slope=slope)
-            gz = ops.conv_gather(d, gz, mod._convs[li].packed("adj", g), mask=a_in)
+            gz = ops.conv_gather(d, gz, mod._convs[li].operand("adj", g, d), mask=a_in)
         ctx.mod, ctx.acts, ctx.prec, ctx.gzs = mod, acts, prec, gzs
         ctx.g_src, ctx.g_cls = g_src, g_cls
         ctx.set_materialize_grads(False)
@@ -240,7 +240,7 @@ class _DBackwardFn(torch.autograd.Function):
             if needs[2 * li + 1] and grad_sink(mod._convs[li].bias, True) is None:
                 out[2 * li + 1] = torch.zeros_like(mod._convs[li].bias)
             d = g.fwd_desc(n, u.shape[1], u.shape[2], precision=prec, mask_slope=slope)
-            u = ops.conv_gather(d, u, mod._convs[li].packed("fwd", g), mask=acts[li + 1])
+            u = ops.conv_gather(d, u, mod._convs[li].operand("fwd", g, d), mask=acts[li + 1])
         if needs[2 * nl] and ctx.g_src is not None:
             sink = grad_sink(mod.conv1.weight, True)
             dw = ops.head_wgrad(ctx.g_src, u, mod._g1.I, 3, 1, dw=sink, accumulate=sink is not None)

@@ -54,6 +54,10 @@ class ConvParams(nn.Module):
             if self.bias is not None:
                 self.bias.uniform_(-bound, bound)
 
+    def operand(self, kind: str, geom: ConvGeom, d) -> torch.Tensor:
+        """The packed weights convolution ``d`` wants: fp32, or three bf16 planes (BF16X3, 128x128 tiles)."""
+        return self.packed(kind + "3" if ops.wants_split_weights(d) else kind, geom)
+
     def packed(self, kind: str, geom: ConvGeom) -> torch.Tensor:
         """Operand layout for the gather kernel, rebuilt when the parameter changed."""
         w = self.weight
@@ -63,7 +67,8 @@ class ConvParams(nn.Module):
             return hit[1]
         with torch.no_grad():
             wd = w.detach().contiguous()
-            t = ops.pack_weight_fwd(wd, geom) if kind == "fwd" else ops.pack_weight_adj(wd, geom)
+            t = {"fwd": ops.pack_weight_fwd, "adj": ops.pack_weight_adj, "fwd3": ops.pack_weight_fwd_x3,
+                 "adj3": ops.pack_weight_adj_x3}[kind](wd, geom)
         self._packed[kind] = (key, t)
         return t
 
@@ -196,10 +201,10 @@ class _GeneratorFn(torch.autograd.Function):
             fuse = nm is not None and not use_running      # statistics ride in the conv's epilogue
             if ly.kind == "conv":
                 d = g.fwd_desc(n, a.shape[1], a.shape[2], precision=prec)
-                wp = ly.conv.packed("fwd", g)
+                wp = ly.conv.operand("fwd", g, d)
             else:
                 d = g.adj_desc(n, a.shape[1], a.shape[2], precision=prec)
-                wp = ly.conv.packed("adj", g)
+                wp = ly.conv.operand("adj", g, d)
             if fuse:
                 z, mean, rstd, varu = ops.conv_gather_stats(d, a, wp, want_var=nm.track)
             else:
@@ -289,15 +294,15 @@ class _GeneratorFn(torch.autograd.Function):
             if li == 0:
                 if need_x:
                     d = gm.adj_desc(n, dz.shape[1], dz.shape[2], precision=prec)
-                    g0 = ops.conv_gather(d, dz, ly.conv.packed("adj", gm))
+                    g0 = ops.conv_gather(d, dz, ly.conv.operand("adj", gm, d))
                     ops.nhwc_to_nchw(g0, x.shape[1], out=gx, accumulate=True)
                 break
             res = pending_res.pop(li, None)
             if ly.kind == "conv":
                 d = gm.adj_desc(n, dz.shape[1], dz.shape[2], precision=prec)
-                g = ops.conv_gather(d, dz, ly.conv.packed("adj", gm), residual=res)
+                g = ops.conv_gather(d, dz, ly.conv.operand("adj", gm, d), residual=res)
             else:
                 d = gm.fwd_desc(n, dz.shape[1], dz.shape[2], precision=prec)
-                g = ops.conv_gather(d, dz, ly.conv.packed("fwd", gm), residual=res)
+                g = ops.conv_gather(d, dz, ly.conv.operand("fwd", gm, d), residual=res)
         ctx.acts = ctx.saved_layers = None
         return (None, gx, None) + tuple(grads)

@@ -122,6 +122,18 @@ class ConvGeom:
         return self.k if self.s == 1 else 2
 
 
+def _check_packed(d: ConvDesc, w_packed: torch.Tensor, K: int) -> None:
+    """fp32 pack, or the three-plane bf16 pack where the descriptor asks for it."""
+    if wants_split_weights(d):
+        L.require_gpu_tensor(w_packed, "w_packed (x3)", torch.bfloat16)
+        want = 3 * d.nphase * d.Cout * K
+    else:
+        L.require_gpu_tensor(w_packed, "w_packed")
+        want = d.nphase * d.Cout * K
+    if w_packed.numel() != want:
+        raise RuntimeError(f"conv: packed weight has {w_packed.numel()} elements, expected {want}")
+
+
 class KernelTimer:
     """HIP-event timing of selected conv_gather launches on the launch stream (bench.py uses it to
     time the dominant kernel inside the real training steps)."""
@@ -145,8 +157,7 @@ def conv_gather(d: ConvDesc, x: torch.Tensor, w_packed: torch.Tensor, bias=None,
     if tuple(x.shape) != exp_in:
         raise RuntimeError(f"conv_gather: input {tuple(x.shape)} != descriptor {exp_in}")
     K = d.KH * d.KW * d.Cin
-    if w_packed.numel() != d.nphase * d.Cout * K:
-        raise RuntimeError(f"conv_gather: packed weight has {w_packed.numel()} elements, expected {d.nphase * d.Cout * K}")
+    _check_packed(d, w_packed, K)
     oshape = (d.N, d.OH, d.OW, d.CoutP)
     if out is None:
         out = torch.empty(oshape, dtype=torch.float32, device=x.device)
@@ -158,7 +169,6 @@ def conv_gather(d: ConvDesc, x: torch.Tensor, w_packed: torch.Tensor, bias=None,
     if bias is not None and bias.numel() != d.Cout:
         raise RuntimeError("conv_gather: bias size")
     L.require_gpu_tensor(x, "x")
-    L.require_gpu_tensor(w_packed, "w_packed")
     wp, wn = _ws(lib.fcd_conv_workspace_bytes(C.byref(d)), x.device)
     timed = KERNEL_TIMER is not None and KERNEL_TIMER.match(d)
     if timed:
@@ -178,10 +188,8 @@ def conv_gather_stats(d: ConvDesc, x: torch.Tensor, w_packed: torch.Tensor, want
     exp_in = (d.N, d.IH, d.IW, d.Cin)
     if tuple(x.shape) != exp_in:
         raise RuntimeError(f"conv_gather_stats: input {tuple(x.shape)} != descriptor {exp_in}")
-    if w_packed.numel() != d.nphase * d.Cout * d.KH * d.KW * d.Cin:
-        raise RuntimeError("conv_gather_stats: packed weight size")
+    _check_packed(d, w_packed, d.KH * d.KW * d.Cin)
     L.require_gpu_tensor(x, "x")
-    L.require_gpu_tensor(w_packed, "w_packed")
     out = torch.empty((d.N, d.OH, d.OW, d.CoutP), dtype=torch.float32, device=x.device)
     mean = torch.empty((d.N, d.CoutP), dtype=torch.float32, device=x.device)
     rstd = torch.empty_like(mean)
@@ -216,6 +224,26 @@ def pack_weight_fwd(w: torch.Tensor, g: ConvGeom) -> torch.Tensor:
     L.require_gpu_tensor(w, "weight")
     out = torch.empty((g.O, g.k, g.k, g.IP), dtype=torch.float32, device=w.device)
     check(L.load().fcd_pack_weight_fwd(ptr(w), ptr(out), g.O, g.I, g.IP, g.k, g.k, stream()), "pack_weight_fwd")
+    return out
+
+
+def wants_split_weights(d: ConvDesc) -> bool:
+    """True where a FCD_PREC_BF16X3 convolution takes three-plane bf16 weights (``*_x3`` packs)."""
+    return bool(L.load().fcd_conv_wants_split_weights(C.byref(d)))
+
+
+def pack_weight_fwd_x3(w: torch.Tensor, g: ConvGeom) -> torch.Tensor:
+    L.require_gpu_tensor(w, "weight")
+    out = torch.empty((3, g.O, g.k, g.k, g.IP), dtype=torch.bfloat16, device=w.device)
+    check(L.load().fcd_pack_weight_fwd_x3(ptr(w), ptr(out), g.O, g.I, g.IP, g.k, g.k, stream()), "pack_weight_fwd_x3")
+    return out
+
+
+def pack_weight_adj_x3(w: torch.Tensor, g: ConvGeom) -> torch.Tensor:
+    L.require_gpu_tensor(w, "weight")
+    t = g.adj_taps()
+    out = torch.empty((g.adj_phases(), 3, g.I, t, t, g.OP), dtype=torch.bfloat16, device=w.device)
+    check(L.load().fcd_pack_weight_adj_x3(ptr(w), ptr(out), g.O, g.OP, g.I, g.k, g.k, g.s, stream()), "pack_weight_adj_x3")
     return out
 
 

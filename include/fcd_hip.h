@@ -121,6 +121,16 @@ int fcd_pack_weight_fwd(const float* w, float* packed, int O, int I, int IP, int
 int fcd_pack_weight_adj(const float* w, float* packed, int O, int OP, int I, int KH, int KW,
                         int stride, void* stream);
 
+/* FCD_PREC_BF16X3: where fcd_conv_wants_split_weights(d) is 1 the convolution takes its weights
+ * already split into three bf16 planes (each fp32 weight = h + m + l, round to nearest at each
+ * level): the same element order as fcd_pack_weight_fwd / _adj, laid out [phase][plane][row][K]
+ * bf16 (6 bytes per weight).  Elsewhere BF16X3 takes the fp32 packs and splits in registers. */
+int fcd_conv_wants_split_weights(const FcdConvDesc* d);
+int fcd_pack_weight_fwd_x3(const float* w, void* packed, int O, int I, int IP, int KH, int KW,
+                           void* stream);
+int fcd_pack_weight_adj_x3(const float* w, void* packed, int O, int OP, int I, int KH, int KW,
+                           int stride, void* stream);
+
 /* Small-Cout convolution heads of the Discriminator (conv1/conv2,
  * fixed_point_gan.py:134-135; stride 1): direct dot products, no MFMA.
  * w_packed = fcd_pack_weight_fwd layout [O][KH][KW][IP]; in NHWC [N][IH][IW][IP];

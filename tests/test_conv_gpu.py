@@ -32,6 +32,15 @@ def to_nhwc(t, cp):
     return out.contiguous()
 
 
+def pack_for(d, w, g, form):
+    """The weight operand descriptor ``d`` wants (three bf16 planes for BF16X3 on 128x128 tiles)."""
+    from fcd_amd import ops
+    x3 = ops.wants_split_weights(d)
+    if form == "fwd":
+        return ops.pack_weight_fwd_x3(w, g) if x3 else ops.pack_weight_fwd(w, g)
+    return ops.pack_weight_adj_x3(w, g) if x3 else ops.pack_weight_adj(w, g)
+
+
 def from_nhwc(t, c):
     return t[..., :c].permute(0, 3, 1, 2).contiguous()
 
@@ -48,8 +57,8 @@ def test_conv_forward(dev, geom, prec):
     b = torch.randn(O)
     ref = F.leaky_relu(F.conv2d(x, w, b, s, p), 0.01)
     xd = to_nhwc(x, g.IP).to(dev)
-    wf = ops.pack_weight_fwd(w.to(dev), g)
     d = g.fwd_desc(N, H, W, precision=prec, act_slope=0.01)
+    wf = pack_for(d, w.to(dev), g, "fwd")
     out = ops.conv_gather(d, xd, wf, bias=b.to(dev))
     torch.cuda.synchronize()
     assert relerr(from_nhwc(out.cpu(), O), ref) <= TOL[prec]
@@ -57,7 +66,7 @@ def test_conv_forward(dev, geom, prec):
     # explicit split-K gives the same answer
     d2 = g.fwd_desc(N, H, W, precision=prec, act_slope=0.01)
     d2.splitk = 3
-    out2 = ops.conv_gather(d2, xd, wf, bias=b.to(dev))
+    out2 = ops.conv_gather(d2, xd, pack_for(d2, w.to(dev), g, "fwd"), bias=b.to(dev))
     assert relerr(from_nhwc(out2.cpu(), O), ref) <= TOL[prec]
 
 
@@ -78,8 +87,8 @@ def test_conv_adjoint(dev, geom, prec):
     mask = torch.randn(N, I, bh, bw)
     res = torch.randn(N, I, bh, bw)
     ref2 = ref * torch.where(mask > 0, 1.0, 0.01) + res
-    wa = ops.pack_weight_adj(w.to(dev), g)
     d = g.adj_desc(N, sh, sw, precision=prec, mask_slope=0.01)
+    wa = pack_for(d, w.to(dev), g, "adj")
     out = ops.conv_gather(d, to_nhwc(gy, g.OP).to(dev), wa)
     assert relerr(from_nhwc(out.cpu(), I), ref) <= TOL[prec]
     out2 = ops.conv_gather(d, to_nhwc(gy, g.OP).to(dev), wa, mask=to_nhwc(mask, g.IP).to(dev),
@@ -121,7 +130,7 @@ STAT_GEOMS = [
 ]
 
 
-@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("prec", [0, 1, 2])
 @pytest.mark.parametrize("geom", STAT_GEOMS)
 def test_conv_with_fused_instnorm_statistics(dev, geom, prec):
     """fcd_conv_gather_stats == fcd_conv_gather followed by fcd_instnorm_stats."""
@@ -133,11 +142,11 @@ def test_conv_with_fused_instnorm_statistics(dev, geom, prec):
     if form == "fwd":
         x = to_nhwc(torch.randn(N, I, H, W) + 0.3, g.IP).to(dev)
         d = g.fwd_desc(N, H, W, precision=prec)
-        wp = ops.pack_weight_fwd(w.to(dev), g)
+        wp = pack_for(d, w.to(dev), g, "fwd")
     else:
         x = to_nhwc(torch.randn(N, O, H, W) + 0.3, g.OP).to(dev)
         d = g.adj_desc(N, H, W, precision=prec)
-        wp = ops.pack_weight_adj(w.to(dev), g)
+        wp = pack_for(d, w.to(dev), g, "adj")
     z0 = ops.conv_gather(d, x, wp)
     m0, r0, v0 = ops.instnorm_stats(z0, want_var=True)
     z1, m1, r1, v1 = ops.conv_gather_stats(d, x, wp, want_var=True)

@@ -10,11 +10,12 @@ g = ops.ConvGeom(256, 256, 3, 1, 1)
 x = torch.randn(n, 256, h, w); wt = torch.randn(256, 256, 3, 3) / 48
 ref = F.conv2d(x.double(), wt.double(), None, 1, 1).permute(0, 2, 3, 1)
 xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
-wf = ops.pack_weight_fwd(wt.to(dev), g)
+wf32 = ops.pack_weight_fwd(wt.to(dev), g)
 gy = torch.randn(n, h, w, 256, device=dev)
 wref = None
 for prec, name in ((0, 'fp32 MFMA'), (2, 'bf16x3'), (1, 'bf16')):
     d = g.fwd_desc(n, h, w, precision=prec)
+    wf = ops.pack_weight_fwd_x3(wt.to(dev), g) if ops.wants_split_weights(d) else wf32
     out = ops.conv_gather(d, xd, wf)
     err = float((out.cpu().double() - ref).norm() / ref.norm())
     mx = float((out.cpu().double() - ref).abs().max() / ref.abs().max())
