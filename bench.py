@@ -65,7 +65,15 @@ def dominant_kernel_roofline(precision, dev, in_step_us=None, in_step_launches=0
     # profiles/r1_e_resblock_conv_pmc_*.csv: FETCH_SIZE 17507 KB x 2 (gfx950 correction) + WRITE_SIZE
     # 16384 KB; algorithmic: 16.8 MB input + 2.4 MB weights + 16.8 MB output.  fp32 launch only.
     traffic = 2 * 17507 * 1024 + 16384 * 1024 if precision in ("fp32", "fp32x3") else None
-    return {"bound": "mfma", "kernel": "conv_gather_dma_kernel<128,128> 3x3 256->256 @32x32 B16",
+    extra = {}
+    if precision == "fp32x3":
+        # six bf16 MFMAs per fp32 product group: the scheme's own ceiling is the bf16 peak / 6
+        peak = round(PEAK_TFLOPS["bf16"] / 6, 1)
+        extra = {"executed_bf16_tflops": round(6 * achieved, 1), "fp32_mfma_peak": PEAK_TFLOPS["fp32"],
+                 "note": "algorithmic fp32 FLOPs; peak = dense bf16 MFMA peak / 6 (six bf16 MFMAs per fp32 product group); "
+                         "the exact-fp32 MFMA pipe peaks at 157.3"}
+        traffic = None      # weights travel as three bf16 planes here; not measured with PMC yet
+    return {**extra, "bound": "mfma", "kernel": "conv_gather_dma_kernel<128,128> 3x3 256->256 @32x32 B16",
             "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
             "us_per_launch": round(ms * 1e3, 2), "launches_timed": in_step_launches,
             "timed": "HIP events around every launch of this kernel in 2 training steps run right after the timed "
@@ -146,7 +154,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--precision", default=os.environ.get("FCD_PRECISION", "fp32"), choices=["fp32", "fp32x3", "bf16"])
+    ap.add_argument("--precision", default=os.environ.get("FCD_PRECISION", "fp32x3"), choices=["fp32", "fp32x3", "bf16"],
+                    help="fp32x3 (default): fp32-faithful convolutions on the bf16 matrix pipe (every fp32 operand split "
+                         "into three bf16 pieces, fp32 accumulate; same parity bars as fp32, error vs fp64 not larger); "
+                         "fp32: exact-fp32 MFMA everywhere; bf16: operands rounded to bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default=os.environ.get("FCD_DIST_BACKEND", "nccl"),
                     help="torch.distributed backend: nccl (= RCCL over xGMI); gloo only to rehearse the "
@@ -226,7 +237,9 @@ def main():
         res = {"metric": "FCD train images/sec (G+D step, 128x128 multispectral)", "value": round(value, 2),
                "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "bf16" if args.precision == "bf16" else "fp32",
+               "dtype": {"fp32": "fp32", "bf16": "bf16 operands, fp32 accumulate",
+                         "fp32x3": "fp32 (conv operands as 3 bf16 pieces on the bf16 MFMA pipe, fp32 accumulate; "
+                                   "fp32-faithful: same parity bars as exact fp32)"}[args.precision],
                "data": "synthetic (numpy PCG64 uint16 patches -> [-1,1], nodata rectangle; random-init weights)",
                "config": {"workload": "FCD G+D train step incl. gradient penalty, batch 16/GPU, 128x128x10, "
                                       "6 res blocks, D x6 (BASELINE.json configs[1])",
@@ -235,6 +248,20 @@ def main():
                "step_tflops": round(GFLOP_PER_IMG * BASE["batch"] / (ms * 1e-3) / 1e3, 2)}
         res["roofline"] = dominant_kernel_roofline(args.precision, dev, timer.mean_us() if timer.pairs else None,
                                                    len(timer.pairs))
+        if args.precision == "fp32x3" and world == 1:
+            # the same step with exact-fp32 MFMA everywhere (v_mfma_f32_32x32x2_f32), for reference
+            solver.set_precision("fp32")
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+            dt1 = time.perf_counter() - t1
+            solver.set_precision(args.precision)
+            res["exact_fp32_mfma"] = {"value": round(BASE["batch"] * args.steps / dt1, 2), "unit": "images/sec",
+                                      "ms_per_step": round(dt1 / args.steps * 1e3, 3)}
         res["roofline_hbm"] = hbm_kernel_roofline(dev)
         res["inference"] = inference_rate(solver, dev)
         if world == 1 and not args.no_cpu_baseline:
