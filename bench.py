@@ -72,7 +72,9 @@ def dominant_kernel_roofline(precision, dev, in_step_us=None, in_step_launches=0
         extra = {"executed_bf16_tflops": round(6 * achieved, 1), "fp32_mfma_peak": PEAK_TFLOPS["fp32"],
                  "note": "algorithmic fp32 FLOPs; peak = dense bf16 MFMA peak / 6 (six bf16 MFMAs per fp32 product group); "
                          "the exact-fp32 MFMA pipe peaks at 157.3"}
-        traffic = None      # weights travel as three bf16 planes here; not measured with PMC yet
+        # profiles/r1_k_resblock_conv_x3_pmc_*.csv: FETCH_SIZE 22136 KB x 2 + WRITE_SIZE 16384 KB (the
+        # weights travel as three bf16 planes: 3.5 MB instead of 2.4 MB per XCD)
+        traffic = 2 * 22136 * 1024 + 16384 * 1024
     return {**extra, "bound": "mfma", "kernel": "conv_gather_dma_kernel<128,128> 3x3 256->256 @32x32 B16",
             "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
             "us_per_launch": round(ms * 1e3, 2), "launches_timed": in_step_launches,

@@ -195,8 +195,15 @@ def conv_gather_stats(d: ConvDesc, x: torch.Tensor, w_packed: torch.Tensor, want
     rstd = torch.empty_like(mean)
     varu = torch.empty_like(mean) if want_var else None
     wp, wn = _ws(lib.fcd_conv_gather_stats_workspace_bytes(C.byref(d)), x.device)
+    timed = KERNEL_TIMER is not None and KERNEL_TIMER.match(d)
+    if timed:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     check(lib.fcd_conv_gather_stats(C.byref(d), ptr(x), ptr(w_packed), ptr(out), ptr(mean), ptr(rstd), ptr(varu), IN_EPS,
                                     wp, wn, stream()), "conv_gather_stats")
+    if timed:       # includes the (few microseconds) finalize kernel that follows the convolution
+        e1.record()
+        KERNEL_TIMER.pairs.append((e0, e1))
     return out, mean, rstd, varu
 
 

@@ -6,8 +6,8 @@ dev = torch.device('cuda:0')
 g = ops.ConvGeom(256, 256, 3, 1, 1)
 n, h, w = 16, 32, 32
 x = torch.randn(n, h, w, 256, device=dev); wt = torch.randn(256, 256, 3, 3, device=dev) / 48
-wf = ops.pack_weight_fwd(wt, g)
 d = g.fwd_desc(n, h, w, precision=prec); d.splitk = sk
+wf = ops.pack_weight_fwd_x3(wt, g) if ops.wants_split_weights(d) else ops.pack_weight_fwd(wt, g)
 out = ops.conv_gather(d, x, wf)
 for _ in range(5): ops.conv_gather(d, x, wf, out=out)
 torch.cuda.synchronize()
