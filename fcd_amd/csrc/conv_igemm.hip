@@ -392,6 +392,82 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
   const int lr = lane & 31, lh = lane >> 5;
   const int lr16 = lane & 15, lg = lane >> 4;
 
+  if constexpr (PREC == FCD_PREC_BF16X3 && !N16 && S == 3) {
+    // Software-pipelined BF16X3 loop: the split of k16-step i+1 (VALU) is issued among the MFMAs of
+    // step i, so the two pipes overlap inside a wave instead of alternating.  Tiles are fetched three
+    // ahead; the one barrier per K-tile sits between the two k16-steps: by then every wave has read
+    // all of tile `it`, whose stage takes the DMA of tile it+3, and tile it+1 has landed for the
+    // split that runs under the second step's MFMAs.
+    struct Pieces { bf16x8_t ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN]; };
+    auto load_split = [&](int stg, int s2, Pieces& P) {
+      const float4* As = smem + stg * STAGE;
+      const float4* Bs = As + BM * 8;
+      const int c0 = 4 * s2 + 2 * lh;
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi) {
+        const int r = wm * WTM + mi * 32 + lr, sw = (r >> 1) & 7;
+        const float4 lo = As[r * 8 + (c0 ^ sw)], hi = As[r * 8 + ((c0 + 1) ^ sw)];
+        split3(f32x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w}, P.ah[mi], P.am[mi], P.al[mi]);
+      }
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni) {
+        if constexpr (BPRE) {
+          const int r = wn * WTN + ni * 32 + lr, c = (2 * s2 + lh) ^ ((r >> 2) & 3);
+          P.bh[ni] = __builtin_bit_cast(bf16x8_t, Bs[(0 * BN + r) * 4 + c]);
+          P.bm[ni] = __builtin_bit_cast(bf16x8_t, Bs[(1 * BN + r) * 4 + c]);
+          P.bl[ni] = __builtin_bit_cast(bf16x8_t, Bs[(2 * BN + r) * 4 + c]);
+        } else {
+          const int r = wn * WTN + ni * 32 + lr, sw = (r >> 1) & 7;
+          const float4 lo = Bs[r * 8 + (c0 ^ sw)], hi = Bs[r * 8 + ((c0 + 1) ^ sw)];
+          split3(f32x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w}, P.bh[ni], P.bm[ni], P.bl[ni]);
+        }
+      }
+    };
+    auto mfma_phase = [&](const Pieces& P, bool with_dma) {
+#pragma unroll
+      for (int pp = 0; pp < 6; ++pp)
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < TN; ++ni) {
+            const bf16x8_t a = pp == 0 ? P.al[mi] : (pp == 2 || pp == 3) ? P.am[mi] : P.ah[mi];
+            const bf16x8_t b = pp == 1 ? P.bl[ni] : (pp == 2 || pp == 4) ? P.bm[ni] : P.bh[ni];
+            if (pp < 5) acc2[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc2[mi][ni], 0, 0, 0);
+            else acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[mi][ni], 0, 0, 0);
+            if (with_dma) {
+              const int g = (pp * TM + mi) * TN + ni;     // 0 .. 6*TM*TN-1
+#pragma unroll
+              for (int q = 0; q < ND; ++q)
+                if (q * (6 * TM * TN) / ND == g) issue_one(q);
+            }
+          }
+    };
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      issue_prepare(s, s < nk);
+#pragma unroll
+      for (int q = 0; q < ND; ++q) issue_one(q);
+      issue_advance();
+    }
+    Pieces P0, P1;
+    wait_vmcnt<2 * ND>();
+    __builtin_amdgcn_s_barrier();
+    load_split(0, 0, P0);
+    int stage = 0;
+    for (int it = 0; it < nk; ++it) {
+      const int next = stage == 2 ? 0 : stage + 1;
+      load_split(stage, 1, P1);         // VALU under ...
+      mfma_phase(P0, false);            // ... the MFMAs of step 0
+      wait_vmcnt<ND>();                 // tile it+1 landed (tile it+2 may fly)
+      __builtin_amdgcn_s_barrier();     // every wave is done reading tile it
+      issue_prepare(stage, it + 3 < nk);
+      load_split(next, 0, P0);          // first step of tile it+1 (zeros past the end) under ...
+      mfma_phase(P1, true);             // ... the MFMAs of step 1, with the DMA of tile it+3 among them
+      issue_advance();
+      stage = next;
+    }
+    wait_vmcnt<0>();
+  } else {
 #pragma unroll
   for (int s = 0; s < S - 1; ++s) {
     issue_prepare(s, s < nk);
@@ -554,6 +630,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
     issue_advance();
     stage = stage + 1 == S ? 0 : stage + 1;
     nstage = nstage + 1 == S ? 0 : nstage + 1;
+  }
   }
   if constexpr (PREC == FCD_PREC_BF16X3) {
 #pragma unroll
