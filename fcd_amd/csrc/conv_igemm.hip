@@ -1284,7 +1284,7 @@ int run_gather(const FcdConvDesc* d, GatherArgs& a, hipStream_t st) {
     a.tiles_n = fcd_cdiv(d->Cout, 128);
     a.w_phase_stride = (long)d->Cout * a.K * 3 / 2;      // three bf16 planes, in units of 4 bytes
     dim3 grid(a.tiles_m * a.tiles_n, a.nphase * a.splitk);
-    hipLaunchKernelGGL((conv_gather_dma_kernel<128, 128, 2, 4, 3, FCD_PREC_BF16X3, false, true>), grid, dim3(512), 0, st, a,
+    hipLaunchKernelGGL((conv_gather_dma_kernel<128, 128, 4, 2, 3, FCD_PREC_BF16X3, false, true>), grid, dim3(512), 0, st, a,
                        (unsigned)((size_t)a.N * a.IH * a.IW * a.Cin * 4), (unsigned)((size_t)a.Cout * a.K * 6));
     rc = fcd_check_launch("conv_gather");
     if (rc) return rc;
