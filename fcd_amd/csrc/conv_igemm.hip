@@ -1324,7 +1324,7 @@ int fused_stats_chunks(const FcdConvDesc* d) {
   int bm, bn;
   gather_tile(d, bm, bn);
   if (bn == 16 || resolve_splitk(d) != 1) return 0;
-  const int wtm = gather_wave_rows(bm, bn);
+  const int wtm = wants_split_weights(d) ? 32 : gather_wave_rows(bm, bn);   // the pre-split kernel runs 4 x 2 waves
   const long ghw = (long)d->GH * d->GW;
   if (ghw % wtm) return 0;
   return (int)(d->nphase * (ghw / wtm));
