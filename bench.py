@@ -253,7 +253,7 @@ def main():
         if args.precision == "fp32x3" and world == 1:
             # the same step with exact-fp32 MFMA everywhere (v_mfma_f32_32x32x2_f32), for reference
             solver.set_precision("fp32")
-            for _ in range(2):
+            for _ in range(20):     # also rides out the clock transient ~1-2 s into a run (tools/sustain_probe.py)
                 step()
             torch.cuda.synchronize()
             t1 = time.perf_counter()

@@ -188,6 +188,9 @@ class FCDSolver(nn.Module):
         for net in (self.G, self.D):
             net.precision = p
             net.wgrad_precision = pw
+            for m in net.modules():          # drop packed weights of the other precision's layout
+                if hasattr(m, "_packed"):
+                    m._packed = {}
         self.precision = precision
 
     @property
