@@ -129,6 +129,34 @@ def inference_rate(solver, dev, iters=5):
             "value": round(64 * iters / dt, 1), "unit": "images/sec", "ms_per_batch": round(dt / iters * 1e3, 2)}
 
 
+def input_pipeline_rate(dev, iters=20):
+    """Input pipeline: a training batch gathered from a uint16 patch pool
+    resident in HBM (random indices, random flips): 20 B read + 40 B written per pixel."""
+    import numpy as np
+    from fcd_amd import ops
+    n, b = 2048, BASE["batch"]
+    rng = np.random.default_rng(5)
+    images = torch.from_numpy(rng.integers(0, 65536, size=(n, BASE["size"], BASE["size"], BASE["bands"]),
+                                           dtype=np.uint16)).to(dev)
+    index = torch.from_numpy(rng.integers(0, n, size=(iters, b))).to(dev)
+    aug = torch.from_numpy(np.concatenate([rng.integers(0, 4, size=(iters, b, 1)), np.zeros((iters, b, 2), np.int64)],
+                                          axis=2).astype(np.int32)).to(dev)
+    ops.patch_batch(images, index[0], aug[0])
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for i in range(iters):
+        ops.patch_batch(images, index[i], aug[i])
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    nbytes = b * BASE["size"] * BASE["size"] * BASE["bands"] * 6.0
+    return {"bound": "hbm", "kernel": "patch_batch_kernel (16 of 2048 patches, 128x128x10 uint16 -> NCHW fp32, flips)",
+            "achieved": round(nbytes / (ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+            "frac": round(nbytes / (ms * 1e-3) / 8e12, 4), "us_per_launch": round(ms * 1e3, 2),
+            "images_per_sec": round(b / (ms * 1e-3), 0)}
+
+
 def cpu_baseline():
     """CPU oracle (port of the reference step: oracle/fcd_oracle.py) on the host cores: one
     G+D step (D-step + G-step + both Adam updates) at B=16, fp32."""
@@ -266,6 +294,7 @@ def main():
                                       "ms_per_step": round(dt1 / args.steps * 1e3, 3)}
         res["roofline_hbm"] = hbm_kernel_roofline(dev)
         res["inference"] = inference_rate(solver, dev)
+        res["input_pipeline"] = input_pipeline_rate(dev)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)

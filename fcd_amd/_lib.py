@@ -99,6 +99,7 @@ PROTOTYPES = {
     "fcd_scene_tiles": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _P, _P]),
     "fcd_scene_stitch": (_I, [_P, _P, _I, _I, _P, _I, _I, _P]),
     "fcd_scene_binarize": (_I, [_P, _P, _I, _I, _I, C.c_double, _P, _P]),
+    "fcd_patch_batch": (_I, [_P, C.c_long, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P]),
     "fcd_valid_minmax": (_I, [_P, _P, C.c_size_t, _P, _P]),
     "fcd_threshold_hist": (_I, [_P, _P, C.c_size_t, _P, _I, _P, _P]),
 }

@@ -123,6 +123,48 @@ __global__ __launch_bounds__(256) void threshold_hist_kernel(const float* __rest
   }
 }
 
+// Training / validation input pipeline: gather a batch of uint16 patches out of a
+// patch pool resident in HBM (prepare_landsat8_biome.py:136-138 layout: images (N,H,W,C) uint16,
+// masks (N,H,W) uint8), apply the per-sample flips and integer translation drawn by the host
+// (data_loader.py:372-374: HorizontalFlip, VerticalFlip, then the shift; uncovered pixels are filled
+// with 0 = nodata), normalise like data_loader.py:375 and write NCHW fp32 (ToTensorV2, :376).
+// aug[b] = {flags (bit 0: horizontal flip, bit 1: vertical flip), dy, dx}.
+__global__ __launch_bounds__(256) void patch_batch_kernel(const uint16_t* __restrict__ images, int H, int W, int C,
+                                                          const long* __restrict__ index, const int* __restrict__ aug, int nb,
+                                                          float* __restrict__ x, const uint8_t* __restrict__ masks,
+                                                          uint8_t* __restrict__ mask_out) {
+  const float rcp = 1.0f / 32767.5f;
+  const long total = (long)nb * H * W;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int px = (int)(idx % W);
+    const long t = idx / W;
+    const int py = (int)(t % H), b = (int)(t / H);
+    int flags = 0, dy = 0, dx = 0;
+    if (aug) { flags = aug[3 * b]; dy = aug[3 * b + 1]; dx = aug[3 * b + 2]; }
+    int sy = py - dy, sx = px - dx;
+    const bool inside = sy >= 0 && sy < H && sx >= 0 && sx < W;
+    if (flags & 2) sy = H - 1 - sy;
+    if (flags & 1) sx = W - 1 - sx;
+    const long spix = (index[b] * H + sy) * W + sx;
+    float* dst = x + ((long)b * C * H + py) * W + px;
+    const long plane = (long)H * W;
+    if ((C & 1) == 0) {            // a pixel's bands as 32-bit pairs (the row is 4-byte aligned when C is even)
+      const uint32_t* src = reinterpret_cast<const uint32_t*>(images + spix * C);
+      for (int k = 0; k < C; k += 2) {
+        const uint32_t v = inside ? src[k >> 1] : 0u;
+        dst[k * plane] = ((float)(v & 0xFFFFu) - 32767.5f) * rcp;
+        dst[(k + 1) * plane] = ((float)(v >> 16) - 32767.5f) * rcp;
+      }
+    } else {
+      for (int k = 0; k < C; ++k) {
+        const float f = inside ? (float)images[spix * C + k] : 0.f;
+        dst[k * plane] = (f - 32767.5f) * rcp;
+      }
+    }
+    if (mask_out) mask_out[idx] = inside ? masks[spix] : (uint8_t)0;
+  }
+}
+
 inline int grid_for(size_t n, int cap = 8192) {
   const size_t b = (n + 255) / 256;
   return (int)(b < 1 ? 1 : (b > (size_t)cap ? cap : b));
@@ -176,4 +218,15 @@ extern "C" int fcd_threshold_hist(const float* diff, const uint8_t* target, size
   hipLaunchKernelGGL(threshold_hist_kernel, dim3(blocks), dim3(256), 0, fcd_stream(stream), diff, target, n, thresholds, T,
                      hist);
   return fcd_check_launch("threshold_hist");
+}
+
+extern "C" int fcd_patch_batch(const uint16_t* images, long n_images, int H, int W, int C, const long* index, const int* aug,
+                               int nb, float* x_nchw, const uint8_t* masks, uint8_t* mask_out, void* stream) {
+  FCD_REQUIRE(images && index && x_nchw, "patch_batch: null pointer");
+  FCD_REQUIRE(n_images > 0 && H > 0 && W > 0 && C > 0 && nb > 0, "patch_batch: bad extents");
+  FCD_REQUIRE((masks == nullptr) == (mask_out == nullptr), "patch_batch: masks and mask_out go together");
+  // index values are validated by the caller (they live in device memory)
+  hipLaunchKernelGGL(patch_batch_kernel, dim3(grid_for((size_t)nb * H * W)), dim3(256), 0, fcd_stream(stream), images, H, W, C,
+                     index, aug, nb, x_nchw, masks, mask_out);
+  return fcd_check_launch("patch_batch");
 }

@@ -547,3 +547,33 @@ def threshold_hist(diff: torch.Tensor, target: torch.Tensor, thresholds: torch.T
     L.require_gpu_tensor(hist, "hist", torch.int64)
     check(L.load().fcd_threshold_hist(ptr(diff), ptr(target), diff.numel(), ptr(thresholds), t, ptr(hist), stream()),
           "threshold_hist")
+
+
+# --------------------------------------------------------------------------- #
+# input pipeline on the device
+# --------------------------------------------------------------------------- #
+def patch_batch(images: torch.Tensor, index: torch.Tensor, aug: Optional[torch.Tensor] = None,
+                masks: Optional[torch.Tensor] = None):
+    """images (N, H, W, C) uint16, index (B,) int64, aug (B, 3) int32 {flags, dy, dx} or None and
+    optional masks (N, H, W) uint8, all on the device -> x (B, C, H, W) fp32 in [-1, 1] and the
+    gathered masks (B, H, W) uint8 (or None)."""
+    L.require_gpu_tensor(images, "images", torch.uint16)
+    L.require_gpu_tensor(index, "index", torch.int64)
+    if images.dim() != 4 or index.dim() != 1:
+        raise ValueError("patch_batch: images must be (N, H, W, C) and index (B,)")
+    n, h, w, c = images.shape
+    b = index.shape[0]
+    if aug is not None:
+        L.require_gpu_tensor(aug, "aug", torch.int32)
+        if tuple(aug.shape) != (b, 3):
+            raise ValueError("patch_batch: aug must be (B, 3)")
+    mask_out = None
+    if masks is not None:
+        L.require_gpu_tensor(masks, "masks", torch.uint8)
+        if tuple(masks.shape) != (n, h, w):
+            raise ValueError("patch_batch: masks must be (N, H, W)")
+        mask_out = torch.empty((b, h, w), dtype=torch.uint8, device=images.device)
+    x = torch.empty((b, c, h, w), dtype=torch.float32, device=images.device)
+    check(L.load().fcd_patch_batch(ptr(images), n, h, w, c, ptr(index), ptr(aug), b, ptr(x), ptr(masks), ptr(mask_out),
+                                   stream()), "patch_batch")
+    return x, mask_out

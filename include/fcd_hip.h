@@ -272,6 +272,23 @@ int fcd_scene_binarize(double* raster, const uint16_t* scene, int H, int W, int 
                        uint8_t* mask, void* stream);
 
 /* ------------------------------------------------------------------------- *
+ * Training / validation input pipeline.  Replaces, for a patch pool
+ * resident in device memory, L8BiomeHDFDataset.__getitem__ + the transform chain of get_dataset
+ * (data_loader.py:287-313, 370-377) + the collate of DataLoader:
+ *   images (n_images,H,W,C) uint16 and optional masks (n_images,H,W) uint8 in the layout of
+ *   prepare_landsat8_biome.py:136-138; index[nb] (device int64) picks the samples; aug (device
+ *   int32 [nb][3] or NULL) = {flags, dy, dx}: bit 0 HorizontalFlip, bit 1 VerticalFlip
+ *   (:372-373), then an integer translation by (dy, dx) whose uncovered pixels are 0 (nodata);
+ *   Normalize(mean .5, std .5, max 65535) (:375) in fp32: (v - 32767.5) * fp32(1/32767.5);
+ *   x_nchw (nb,C,H,W) fp32 (ToTensorV2, :376); mask_out (nb,H,W) uint8 gets the same geometry.
+ * The host draws the random parameters; sub-pixel translation (albumentations Affine's
+ * interpolation) is not reproduced.
+ * ------------------------------------------------------------------------- */
+int fcd_patch_batch(const uint16_t* images, long n_images, int H, int W, int C, const long* index,
+                    const int* aug, int nb, float* x_nchw, const uint8_t* masks, uint8_t* mask_out,
+                    void* stream);
+
+/* ------------------------------------------------------------------------- *
  * Threshold search (fcd_solver.py:680-725, metrics.py:4-15).
  * target: 0 = invalid, 1 = clear, 2 = cloudy (class = target - 1).
  * fcd_valid_minmax folds min / max of diff over valid pixels into minmax[2]

@@ -354,6 +354,42 @@ def normalize_u16(v: np.ndarray) -> np.ndarray:
     return t
 
 
+def patch_batch(images: np.ndarray, index: np.ndarray, aug: Optional[np.ndarray] = None,
+                masks: Optional[np.ndarray] = None):
+    """Batch assembly of the train / validation loader: ``L8BiomeHDFDataset.__getitem__``
+    (``data_loader.py:287-313``) through the transform chain of ``get_dataset`` (``:370-377``) and
+    DataLoader's collate.  images (N,H,W,C) uint16, masks (N,H,W) uint8; aug[b] = (flags, dy, dx):
+    HorizontalFlip (bit 0, ``img[:, ::-1]``), VerticalFlip (bit 1, ``img[::-1]``), then a whole-pixel
+    translation whose uncovered pixels are 0; Normalize; HWC -> CHW.  Returns (x fp32 (B,C,H,W),
+    masks uint8 (B,H,W) or None)."""
+    xs, ms = [], []
+    for b, i in enumerate(index):
+        img = images[i]
+        m = masks[i] if masks is not None else None
+        flags, dy, dx = (0, 0, 0) if aug is None else (int(v) for v in aug[b])
+        if flags & 1:
+            img = img[:, ::-1]
+            m = m[:, ::-1] if m is not None else None
+        if flags & 2:
+            img = img[::-1]
+            m = m[::-1] if m is not None else None
+        if dy or dx:
+            h, w = img.shape[:2]
+            sh = np.zeros_like(img)
+            ys, yd = (slice(0, h - dy), slice(dy, h)) if dy >= 0 else (slice(-dy, h), slice(0, h + dy))
+            xsrc, xdst = (slice(0, w - dx), slice(dx, w)) if dx >= 0 else (slice(-dx, w), slice(0, w + dx))
+            sh[yd, xdst] = img[ys, xsrc]
+            img = sh
+            if m is not None:
+                shm = np.zeros_like(m)
+                shm[yd, xdst] = m[ys, xsrc]
+                m = shm
+        xs.append(np.transpose(normalize_u16(np.ascontiguousarray(img)), (2, 0, 1)))
+        if m is not None:
+            ms.append(np.ascontiguousarray(m))
+    return np.stack(xs), (np.stack(ms) if masks is not None else None)
+
+
 def scene_patches(h: int, w: int, patch: int, crop: int = 0):
     """Row-major (row, col) patch origins and reflect-pad amounts.
     Reference ``data_loader.py:83-95``."""

@@ -110,3 +110,33 @@ def test_bucket_plan():
     assert plan_buckets([10, 10, 10, 50, 5], 25) == [[0, 1], [2], [3], [4]]
     assert plan_buckets([], 10) == []
     assert plan_buckets([100], 10) == [[0]]
+
+
+def test_on_before_batch_transfer_and_oracle_patch_batch():
+    """Host half of the input pipeline (data_loader.py:56-71) and the numpy restatement of the
+    batch assembly: flips are involutions, a shift moves pixels and fills with nodata."""
+    import numpy as np
+    from fcd_amd.data_loader import on_before_batch_transfer
+    from oracle import fcd_oracle as O
+    batch = {"image": torch.zeros(5, 10, 8, 8), "label": torch.tensor([0., 1., 1., 0., 1.]), "mask": torch.zeros(5, 8, 8)}
+    out = on_before_batch_transfer(batch, generator=torch.Generator().manual_seed(3))
+    assert len(out) == 6
+    x, c_org, c_trg, l_org, l_trg, m = out
+    perm = torch.randperm(5, generator=torch.Generator().manual_seed(3))
+    assert l_org.shape == (5, 1) and torch.equal(l_trg, l_org[perm]) and torch.equal(c_trg, l_trg)
+    assert len(on_before_batch_transfer({"image": batch["image"], "label": batch["label"]})) == 5
+
+    rng = np.random.default_rng(0)
+    images = rng.integers(0, 65536, size=(3, 6, 5, 4), dtype=np.uint16)
+    masks = rng.integers(0, 3, size=(3, 6, 5), dtype=np.uint8)
+    idx = np.array([2, 0])
+    x0, m0 = O.patch_batch(images, idx, None, masks)
+    assert x0.shape == (2, 4, 6, 5) and x0.dtype == np.float32
+    assert np.array_equal(x0[0], np.transpose(O.normalize_u16(images[2]), (2, 0, 1)))
+    xh, mh = O.patch_batch(images, idx, np.array([[1, 0, 0], [2, 0, 0]]), masks)
+    assert np.array_equal(xh[0], x0[0][:, :, ::-1]) and np.array_equal(xh[1], x0[1][:, ::-1, :])
+    assert np.array_equal(mh[0], m0[0][:, ::-1]) and np.array_equal(mh[1], m0[1][::-1, :])
+    xs, ms = O.patch_batch(images, idx, np.array([[0, 2, -1], [0, 0, 0]]), masks)
+    assert np.array_equal(xs[0][:, 2:, :-1], x0[0][:, :-2, 1:])
+    assert (xs[0][:, :2, :] == -1.0).all() and (xs[0][:, :, -1] == -1.0).all()
+    assert (ms[0][:2] == 0).all() and np.array_equal(ms[0][2:, :-1], m0[0][:-2, 1:])
