@@ -51,10 +51,13 @@ def input_grad_only():
 
 
 class _ConvAct(nn.Sequential):
-    """``Sequential(Conv2d, act)``: index 0 holds the parameters (key ``*.0.weight``)."""
+    """``Sequential(Conv2d, act)``: index 0 holds the parameters (key ``*.0.weight``); with
+    ``interm_non_act`` the reference builds ``Sequential(act, Conv2d)`` (key ``*.1.weight``)."""
 
-    def __init__(self, cin, cout):
-        super().__init__(ConvParams((cout, cin, 4, 4), cin * 16, bias=True), nn.Identity())
+    def __init__(self, cin, cout, act_first=False):
+        conv = ConvParams((cout, cin, 4, 4), cin * 16, bias=True)
+        super().__init__(*((nn.Identity(), conv) if act_first else (conv, nn.Identity())))
+        self.conv_index = 1 if act_first else 0
 
 
 class Discriminator(nn.Module):
@@ -63,12 +66,13 @@ class Discriminator(nn.Module):
     def __init__(self, image_size=128, conv_dim=64, c_dim=5, repeat_num=6, num_channels=3, activation="lrelu",
                  n_feature_layers=4, interm_non_act=False, use_attention=False):
         super().__init__()
-        if interm_non_act or use_attention:
-            # off by default (fcd_main.py:144,147); outside the hot path
-            raise NotImplementedError("interm_non_act / use_attention have no HIP path")
+        if use_attention:
+            # off by default (fcd_main.py:147); outside the hot path
+            raise NotImplementedError("use_attention has no HIP path")
+        # relu / lrelu: the backward masks come from the sign of the stored output (y > 0 <=> z > 0;
+        # at z == 0 both torch and this path take the negative-side slope)
         self.slope = _act_slope(activation)
-        if self.slope <= 0.0:
-            raise NotImplementedError("D needs an activation with positive slope (masks come from the output sign)")
+        self.interm_non_act = bool(interm_non_act)
         self.image_size, self.c_dim, self.num_channels = image_size, c_dim, num_channels
         self.precision = L.PREC_F32
         self.wgrad_precision = None          # None: same as precision
@@ -76,7 +80,7 @@ class Discriminator(nn.Module):
         geoms = []
         cin, cout = num_channels, conv_dim
         for _ in range(repeat_num):
-            layers.append(_ConvAct(cin, cout))
+            layers.append(_ConvAct(cin, cout, act_first=self.interm_non_act))
             geoms.append(ConvGeom(cout, cin, 4, 2, 1))
             cin, cout = cout, cout * 2
         ks = int(image_size / np.power(2, repeat_num))
@@ -85,8 +89,17 @@ class Discriminator(nn.Module):
         self.main = nn.Sequential(*rest) if len(rest) > 0 else nn.Identity()
         self.conv1 = ConvParams((1, cin, 3, 3), cin * 9)
         self.conv2 = ConvParams((c_dim, cin, ks, ks), cin * ks * ks)
-        self._convs = [m[0] for m in layers]
+        self._convs = [m[m.conv_index] for m in layers]
         self._geoms = geoms
+        # interm_non_act (fixed_point_gan.py:108-111) builds every layer as act(inplace) -> conv.  The
+        # in-place activation rewrites the previous layer's output, so every intermediate tensor --
+        # the returned feature map included, as long as `main` is not empty -- ends up activated
+        # exactly as in the default network; the one difference is that the LAST convolution's
+        # output reaches the heads (and, when n_feature_layers >= repeat_num, the feature list)
+        # without activation.  slope 1.0 = identity.
+        self._slopes = [self.slope] * repeat_num
+        if self.interm_non_act and repeat_num > 0:
+            self._slopes[-1] = 1.0
         self._n_feat = min(n_feature_layers, len(layers))
         self._g1 = ConvGeom(1, cin, 3, 1, 1)
         self._g2 = ConvGeom(c_dim, cin, ks, 1, 0)
@@ -116,7 +129,7 @@ class _DiscriminatorFn(torch.autograd.Function):
         acts = [ops.nchw_to_nhwc(x, mod._geoms[0].IP)]
         for li, (cv, g) in enumerate(zip(mod._convs, mod._geoms)):
             a = acts[-1]
-            d = g.fwd_desc(n, a.shape[1], a.shape[2], precision=prec, act_slope=mod.slope)
+            d = g.fwd_desc(n, a.shape[1], a.shape[2], precision=prec, act_slope=mod._slopes[li])
             acts.append(ops.conv_gather(d, a, cv.operand("fwd", g, d), bias=params[2 * li + 1]))
         top = acts[-1]
         if top.shape[1] < mod._g2.k or top.shape[2] < mod._g2.k:
@@ -150,14 +163,19 @@ class _DBackwardFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mod: Discriminator, acts, prec, want_x, want_params, g_src, g_cls, g_feat, *params):
         n = acts[0].shape[0]
-        slope = mod.slope
+        slopes = mod._slopes
+        slope = slopes[-1]               # activation in front of the heads
         prec_w = prec if mod.wgrad_precision is None else mod.wgrad_precision
         top = acts[-1]
         nl = len(mod._convs)
         dev = top.device
         grads: List[Optional[torch.Tensor]] = [None] * (2 * nl + 2)
+        # Only the feature map is used downstream (feature-matching loss of a frozen D,
+        # fcd_solver.py:361-385): start at the feature layer instead of pushing zeros through the
+        # layers above it.
+        only_feat = g_src is None and g_cls is None and g_feat is not None and not want_params
         # heads -> masked gradient at the top activation
-        gz = torch.empty_like(top)
+        gz = None if only_feat else torch.empty_like(top)
         first = True
         if g_src is not None:
             g_src = g_src.contiguous()
@@ -175,17 +193,17 @@ class _DBackwardFn(torch.autograd.Function):
                 sink = grad_sink(mod.conv2.weight, True)
                 dw = ops.head_wgrad(g_cls4, top, mod._g2.I, mod._g2.k, 0, dw=sink, accumulate=sink is not None)
                 grads[2 * nl + 1] = None if sink is not None else dw
-        if first:
+        if first and gz is not None:
             gz.zero_()
         gzs = [None] * nl          # gzs[l] = masked gradient at layer l's pre-activation
         gx = None
-        for li in range(nl - 1, -1, -1):
+        for li in range(mod._n_feat - 1 if only_feat else nl - 1, -1, -1):
             if g_feat is not None and li == mod._n_feat - 1:
                 # gradient arriving at the exposed feature map: mask it and add
                 gf = ops.nchw_to_nhwc(g_feat.contiguous(), acts[li + 1].shape[3])
-                L.check(L.load().fcd_lrelu_bwd(L.ptr(gf), L.ptr(acts[li + 1]), L.ptr(gf), gf.numel(), slope,
+                L.check(L.load().fcd_lrelu_bwd(L.ptr(gf), L.ptr(acts[li + 1]), L.ptr(gf), gf.numel(), slopes[li],
                                                L.stream()), "lrelu_bwd")
-                gz = gz + gf
+                gz = gf if gz is None else gz + gf
             gzs[li] = gz
             g = mod._geoms[li]
             a_in = acts[li]
@@ -205,7 +223,7 @@ class _DBackwardFn(torch.autograd.Function):
                     g0 = ops.conv_gather(d, gz, mod._convs[0].operand("adj", g, d))
                     gx = ops.nhwc_to_nchw(g0, mod.num_channels)
                 break
-            d = g.adj_desc(n, gz.shape[1], gz.shape[2], precision=prec, mask_slope=slope)
+            d = g.adj_desc(n, gz.shape[1], gz.shape[2], precision=prec, mask_slope=slopes[li - 1])
             gz = ops.conv_gather(d, gz, mod._convs[li].operand("adj", g, d), mask=a_in)
         ctx.mod, ctx.acts, ctx.prec, ctx.gzs = mod, acts, prec, gzs
         ctx.g_src, ctx.g_cls = g_src, g_cls
@@ -228,18 +246,19 @@ class _DBackwardFn(torch.autograd.Function):
         if gg_x is None:
             return (None,) * 8 + tuple(out)
         n = acts[0].shape[0]
-        slope = mod.slope
         u = ops.nchw_to_nhwc(gg_x.contiguous(), mod._geoms[0].IP)
         for li in range(nl):
             g = mod._geoms[li]
             if needs[2 * li]:
+                if gzs[li] is None:
+                    raise NotImplementedError("double backward through a feature-only backward of D")
                 sink = grad_sink(mod._convs[li].weight, True)
                 wd = g.wgrad_desc(n, u.shape[1], u.shape[2], precision=prec_w, accumulate=sink is not None)
                 dw = ops.conv_wgrad(wd, gzs[li], u, dw=sink)
                 out[2 * li] = None if sink is not None else dw
             if needs[2 * li + 1] and grad_sink(mod._convs[li].bias, True) is None:
                 out[2 * li + 1] = torch.zeros_like(mod._convs[li].bias)
-            d = g.fwd_desc(n, u.shape[1], u.shape[2], precision=prec, mask_slope=slope)
+            d = g.fwd_desc(n, u.shape[1], u.shape[2], precision=prec, mask_slope=mod._slopes[li])
             u = ops.conv_gather(d, u, mod._convs[li].operand("fwd", g, d), mask=acts[li + 1])
         if needs[2 * nl] and ctx.g_src is not None:
             sink = grad_sink(mod.conv1.weight, True)

@@ -154,8 +154,12 @@ class FCDSolver(nn.Module):
             setattr(self, k, getattr(config, k))
         self.act_G, self.act_D = config.act_G, config.act_D
         self.n_feature_layers = config.n_feat_layers
-        if getattr(config, "use_feats", False) or getattr(config, "use_vgg", False):
-            raise NotImplementedError("use_feats / use_vgg are outside the HIP hot path (SURVEY section 2 row 10)")
+        if getattr(config, "use_vgg", False):
+            raise NotImplementedError("use_vgg (a torchvision VGG feature loss) is outside the HIP hot path "
+                                      "(SURVEY section 2 row 10)")
+        self.use_feats = bool(getattr(config, "use_feats", False))
+        self.lambda_feat = float(getattr(config, "lambda_feat", 1.0))      # fcd_main.py:90
+        self.interm_non_act = bool(getattr(config, "interm_non_act", False))
         self.threshold = 0.027                      # fcd_solver.py:79
         self.global_step = 0
         self.loss_dict: Dict[str, torch.Tensor] = {}
@@ -175,7 +179,8 @@ class FCDSolver(nn.Module):
         """Create a generator and a discriminator (``fcd_solver.py:150-164``, init_type 'none')."""
         self.G = Generator(self.g_conv_dim, self.c_dim, self.g_repeat_num, self.num_channels, activation=self.act_G)
         self.D = Discriminator(self.image_size, self.d_conv_dim, self.c_dim, self.d_repeat_num, self.num_channels,
-                               activation=self.act_D, n_feature_layers=self.n_feature_layers)
+                               activation=self.act_D, n_feature_layers=self.n_feature_layers,
+                               interm_non_act=self.interm_non_act)
 
     def set_precision(self, precision: str):
         """'fp32': exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere.
@@ -230,6 +235,11 @@ class FCDSolver(nn.Module):
             return losses.bce_logits_mean(logit, target)
         raise NotImplementedError(dataset)
 
+    @staticmethod
+    def _feat_l1(real_feats, other_feats):
+        terms = [losses.l1_mean(a.detach(), b) for a, b in zip(real_feats, other_feats)]
+        return terms[0] if len(terms) == 1 else torch.mean(torch.stack(terms))
+
     def _alpha(self, b, device):
         if self.alpha_override is not None:
             return self.alpha_override.to(device).contiguous().float()
@@ -269,7 +279,7 @@ class FCDSolver(nn.Module):
                 g_loss_cls = self.classification_loss(out_cls, label_trg, self.dataset)
 
                 x_fake_id = self.G(x_real, c_org)
-                out_src_id, out_cls_id, _ = self.D(x_fake_id)
+                out_src_id, out_cls_id, x_fake_id_feats = self.D(x_fake_id)
                 g_loss_fake_id = losses.mean_scaled(out_src_id, -1.0)
                 g_loss_cls_id = self.classification_loss(out_cls_id, label_org, self.dataset)
                 g_loss_id = losses.l1_mean(x_real, x_fake_id)
@@ -278,12 +288,29 @@ class FCDSolver(nn.Module):
                 g_loss_rec = losses.l1_mean(x_real, x_reconst)
 
                 x_reconst_id = self.G(x_fake_id, c_org)
-                _ = self.D(x_reconst_id)    # reference :358 (outputs feed only the feature-matching loss)
+                _, _, x_reconst_id_feats = self.D(x_reconst_id)    # reference :358
                 g_loss_rec_id = losses.l1_mean(x_real, x_reconst_id)
+
+                if self.use_feats:
+                    # feature matching on D's exposed feature map (fcd_solver.py:361-385; the list has
+                    # one entry, so mean(stack([m])) == m)
+                    _, _, x_real_feats = self.D(x_real)
+                    g_loss_id_feat = self._feat_l1(x_real_feats, x_fake_id_feats)
+                    _, _, x_reconst_feats = self.D(x_reconst)
+                    g_loss_rec_feat = self._feat_l1(x_real_feats, x_reconst_feats)
+                    g_loss_rec_id_feat = self._feat_l1(x_real_feats, x_reconst_id_feats)
+                    g_loss_feat = (self.lambda_feat * self.lambda_rec * g_loss_rec_feat
+                                   + self.lambda_feat * self.lambda_rec * g_loss_rec_id_feat
+                                   + self.lambda_feat * self.lambda_id * g_loss_id_feat)
 
                 g_loss_same = (g_loss_fake_id + self.lambda_rec * g_loss_rec_id + self.lambda_cls * g_loss_cls_id
                                + self.lambda_id * g_loss_id)
                 loss = g_loss_fake + self.lambda_rec * g_loss_rec + self.lambda_cls * g_loss_cls + g_loss_same
+                if self.use_feats:
+                    loss = loss + g_loss_feat
+                    loss_dict["G/loss_id_feat"] = g_loss_id_feat
+                    loss_dict["G/loss_rec_feat"] = g_loss_rec_feat
+                    loss_dict["G/loss_rec_id_feat"] = g_loss_rec_id_feat
                 loss_dict["G/loss_fake"] = g_loss_fake
                 loss_dict["G/loss_rec"] = g_loss_rec
                 loss_dict["G/loss_cls"] = g_loss_cls

@@ -153,13 +153,22 @@ def discriminator_convs(sd: StateDict) -> List[str]:
     return names, i
 
 
-def discriminator_forward(sd: StateDict, x: Tensor, activation: str = "lrelu"):
-    """(out_src, out_cls, [feat]) = D(x).  Reference ``fixed_point_gan.py:137-144``."""
+def discriminator_forward(sd: StateDict, x: Tensor, activation: str = "lrelu", interm_non_act: bool = False):
+    """(out_src, out_cls, [feat]) = D(x).  Reference ``fixed_point_gan.py:137-144``.
+
+    ``interm_non_act`` (``:108-111``) builds each layer as ``act(inplace=True) -> conv``.  The
+    in-place activation overwrites the previous layer's output -- including the tensor already
+    appended to the feature list -- so every intermediate ends up activated as in the default
+    network; only the last convolution's output stays un-activated (it feeds the heads, and it is
+    the returned feature when ``n_feature_layers >= repeat_num``).  Pinned against the reference
+    module in ``make_golden.py --variants``."""
     names, n_feat = discriminator_convs(sd)
     h = x
     feat = None
     for k, p in enumerate(names):
-        h = _act(activation, F.conv2d(h, sd[p + ".weight"], sd[p + ".bias"], 2, 1))
+        h = F.conv2d(h, sd[p + ".weight"], sd[p + ".bias"], 2, 1)
+        if not (interm_non_act and k == len(names) - 1):
+            h = _act(activation, h)
         if k == n_feat - 1:
             feat = h
     out_src = F.conv2d(h, sd["conv1.weight"], None, 1, 1)
@@ -198,7 +207,7 @@ def _leaf_params(sd: StateDict, grad: bool) -> StateDict:
 
 def d_step(g_sd: StateDict, d_sd: StateDict, batch, alpha: Tensor,
            lambdas=DEFAULT_LAMBDAS, act_g: str = "relu", act_d: str = "lrelu",
-           new_stats: Optional[StateDict] = None):
+           new_stats: Optional[StateDict] = None, interm_non_act: bool = False):
     """Discriminator loss graph, ``fcd_solver.py:279-308`` with ``alpha`` injected.
 
     Lightning's ``toggle_optimizer`` freezes G for this step, so only D leaves
@@ -206,16 +215,17 @@ def d_step(g_sd: StateDict, d_sd: StateDict, batch, alpha: Tensor,
     """
     x_real, c_org, c_trg, label_org, label_trg = batch
     d = _leaf_params(d_sd, True)
-    out_src, out_cls, _ = discriminator_forward(d, x_real, act_d)
+    ina = interm_non_act
+    out_src, out_cls, _ = discriminator_forward(d, x_real, act_d, ina)
     d_loss_real = -torch.mean(out_src)
     d_loss_cls = classification_loss(out_cls, label_org)
     with torch.no_grad():
         x_fake = generator_forward(g_sd, x_real, c_trg, True, act_g, new_stats)
-    out_src, _, _ = discriminator_forward(d, x_fake.detach(), act_d)
+    out_src, _, _ = discriminator_forward(d, x_fake.detach(), act_d, ina)
     d_loss_fake = torch.mean(out_src)
     alpha = alpha.to(x_real.dtype)
     x_hat = (alpha * x_real + (1 - alpha) * x_fake).detach().requires_grad_(True)
-    out_src, _, _ = discriminator_forward(d, x_hat, act_d)
+    out_src, _, _ = discriminator_forward(d, x_hat, act_d, ina)
     d_loss_gp = gradient_penalty(out_src, x_hat)
     loss = d_loss_real + d_loss_fake + lambdas["cls"] * d_loss_cls + lambdas["gp"] * d_loss_gp
     names = [k for k, v in d.items() if v.requires_grad]
@@ -228,20 +238,27 @@ def d_step(g_sd: StateDict, d_sd: StateDict, batch, alpha: Tensor,
 
 def g_step(g_sd: StateDict, d_sd: StateDict, batch, lambdas=DEFAULT_LAMBDAS,
            act_g: str = "relu", act_d: str = "lrelu",
-           new_stats: Optional[StateDict] = None):
-    """Generator loss graph, ``fcd_solver.py:316-359, 404-406`` (use_feats/use_vgg off,
-    use_mask hard-wired False at :341).  D is frozen (Lightning toggle)."""
+           new_stats: Optional[StateDict] = None, use_feats: bool = False, lambda_feat: float = 1.0,
+           interm_non_act: bool = False):
+    """Generator loss graph, ``fcd_solver.py:316-359, 404-406``; ``use_feats`` adds the
+    feature-matching terms of ``:361-385`` (use_vgg off, use_mask hard-wired False at :341).
+    D is frozen (Lightning toggle)."""
+    ina = interm_non_act
+
+    def feat_l1(fa, fb):
+        return torch.mean(torch.stack([torch.mean(torch.abs(a - b)) for a, b in zip(fa, fb)]))
+
     x_real, c_org, c_trg, label_org, label_trg = batch
     g = _leaf_params(g_sd, True)
     if new_stats is None:
         new_stats = {}
     x_fake = generator_forward(g, x_real, c_trg, True, act_g, new_stats)
-    out_src, out_cls, _ = discriminator_forward(d_sd, x_fake, act_d)
+    out_src, out_cls, _ = discriminator_forward(d_sd, x_fake, act_d, ina)
     g_loss_fake = -torch.mean(out_src)
     g_loss_cls = classification_loss(out_cls, label_trg)
 
     x_fake_id = generator_forward(g, x_real, c_org, True, act_g, new_stats)
-    out_src_id, out_cls_id, _ = discriminator_forward(d_sd, x_fake_id, act_d)
+    out_src_id, out_cls_id, x_fake_id_feats = discriminator_forward(d_sd, x_fake_id, act_d, ina)
     g_loss_fake_id = -torch.mean(out_src_id)
     g_loss_cls_id = classification_loss(out_cls_id, label_org)
     g_loss_id = torch.mean(torch.abs(x_real - x_fake_id))
@@ -255,11 +272,22 @@ def g_step(g_sd: StateDict, d_sd: StateDict, batch, lambdas=DEFAULT_LAMBDAS,
     g_loss_same = (g_loss_fake_id + lambdas["rec"] * g_loss_rec_id
                    + lambdas["cls"] * g_loss_cls_id + lambdas["id"] * g_loss_id)
     loss = g_loss_fake + lambdas["rec"] * g_loss_rec + lambdas["cls"] * g_loss_cls + g_loss_same
-    names = [k for k, v in g.items() if v.requires_grad]
-    grads = torch.autograd.grad(loss, [g[k] for k in names])
     losses = {"G/loss_fake": g_loss_fake, "G/loss_rec": g_loss_rec, "G/loss_cls": g_loss_cls,
               "G/loss_fake_id": g_loss_fake_id, "G/loss_rec_id": g_loss_rec_id,
               "G/loss_cls_id": g_loss_cls_id, "G/loss_id": g_loss_id}
+    if use_feats:
+        _, _, x_reconst_id_feats = discriminator_forward(d_sd, x_reconst_id, act_d, ina)
+        _, _, x_real_feats = discriminator_forward(d_sd, x_real, act_d, ina)
+        _, _, x_reconst_feats = discriminator_forward(d_sd, x_reconst, act_d, ina)
+        g_loss_id_feat = feat_l1(x_real_feats, x_fake_id_feats)
+        g_loss_rec_feat = feat_l1(x_real_feats, x_reconst_feats)
+        g_loss_rec_id_feat = feat_l1(x_real_feats, x_reconst_id_feats)
+        loss = loss + (lambda_feat * lambdas["rec"] * g_loss_rec_feat + lambda_feat * lambdas["rec"] * g_loss_rec_id_feat
+                       + lambda_feat * lambdas["id"] * g_loss_id_feat)
+        losses.update({"G/loss_id_feat": g_loss_id_feat, "G/loss_rec_feat": g_loss_rec_feat,
+                       "G/loss_rec_id_feat": g_loss_rec_id_feat})
+    names = [k for k, v in g.items() if v.requires_grad]
+    grads = torch.autograd.grad(loss, [g[k] for k in names])
     return loss.detach(), {k: v.detach() for k, v in losses.items()}, dict(zip(names, grads))
 
 

@@ -13,6 +13,7 @@ Fixtures are data (inputs / expected outputs); no reference source is stored.
 import argparse
 import json
 import os
+import re
 import sys
 import zlib
 
@@ -33,9 +34,10 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 LAM = O.DEFAULT_LAMBDAS
 
 
-def ref_modules(gs, ds, cfg):
-    G = Generator(cfg["g_conv_dim"], cfg["c_dim"], cfg["g_repeat"], cfg["bands"])
-    D = Discriminator(cfg["size"], cfg["d_conv_dim"], cfg["c_dim"], cfg["d_repeat"], cfg["bands"])
+def ref_modules(gs, ds, cfg, act_g="relu", act_d="lrelu", n_feat=4, interm_non_act=False):
+    G = Generator(cfg["g_conv_dim"], cfg["c_dim"], cfg["g_repeat"], cfg["bands"], activation=act_g)
+    D = Discriminator(cfg["size"], cfg["d_conv_dim"], cfg["c_dim"], cfg["d_repeat"], cfg["bands"], activation=act_d,
+                      n_feature_layers=n_feat, interm_non_act=interm_non_act)
     G.load_state_dict(gs)
     D.load_state_dict(ds)
     return G, D
@@ -69,7 +71,7 @@ def ref_d_step(G, D, batch, alpha):
     return loss.detach(), {k: v.detach() for k, v in losses.items()}, grads
 
 
-def ref_g_step(G, D, batch):
+def ref_g_step(G, D, batch, use_feats=False, lambda_feat=1.0):
     x_real, c_org, c_trg, label_org, label_trg = batch
     G.requires_grad_(True); D.requires_grad_(False)
     G.train(); D.train()
@@ -79,22 +81,34 @@ def ref_g_step(G, D, batch):
     l_fake = -torch.mean(out_src)
     l_cls = F.binary_cross_entropy_with_logits(out_cls, label_trg)
     x_fake_id = G(x_real, c_org)
-    out_src_id, out_cls_id, _ = D(x_fake_id)
+    out_src_id, out_cls_id, x_fake_id_feats = D(x_fake_id)
     l_fake_id = -torch.mean(out_src_id)
     l_cls_id = F.binary_cross_entropy_with_logits(out_cls_id, label_org)
     l_id = torch.mean(torch.abs(x_real - x_fake_id))
     x_reconst = G(x_fake, c_org)
     l_rec = torch.mean(torch.abs(x_real - x_reconst))
     x_reconst_id = G(x_fake_id, c_org)
-    _ = D(x_reconst_id)
+    _, _, x_reconst_id_feats = D(x_reconst_id)
     l_rec_id = torch.mean(torch.abs(x_real - x_reconst_id))
-    same = l_fake_id + LAM["rec"] * l_rec_id + LAM["cls"] * l_cls_id + LAM["id"] * l_id
-    loss = l_fake + LAM["rec"] * l_rec + LAM["cls"] * l_cls + same
-    loss.backward()
-    grads = {k: p.grad.clone() for k, p in G.named_parameters()}
     losses = {"G/loss_fake": l_fake, "G/loss_rec": l_rec, "G/loss_cls": l_cls,
               "G/loss_fake_id": l_fake_id, "G/loss_rec_id": l_rec_id,
               "G/loss_cls_id": l_cls_id, "G/loss_id": l_id}
+    l_feat = 0
+    if use_feats:      # the arithmetic of fcd_solver.py:361-385 (use_mask False)
+        def fl1(fa, fb):
+            return torch.mean(torch.stack([torch.mean(torch.abs(a - b)) for a, b in zip(fa, fb)]))
+        _, _, x_real_feats = D(x_real)
+        l_id_feat = fl1(x_real_feats, x_fake_id_feats)
+        _, _, x_reconst_feats = D(x_reconst)
+        l_rec_feat = fl1(x_real_feats, x_reconst_feats)
+        l_rec_id_feat = fl1(x_real_feats, x_reconst_id_feats)
+        l_feat = lambda_feat * LAM["rec"] * l_rec_feat + lambda_feat * LAM["rec"] * l_rec_id_feat \
+            + lambda_feat * LAM["id"] * l_id_feat
+        losses.update({"G/loss_id_feat": l_id_feat, "G/loss_rec_feat": l_rec_feat, "G/loss_rec_id_feat": l_rec_id_feat})
+    same = l_fake_id + LAM["rec"] * l_rec_id + LAM["cls"] * l_cls_id + LAM["id"] * l_id
+    loss = l_fake + LAM["rec"] * l_rec + LAM["cls"] * l_cls + same + l_feat
+    loss.backward()
+    grads = {k: p.grad.clone() for k, p in G.named_parameters()}
     return loss.detach(), {k: v.detach() for k, v in losses.items()}, grads
 
 
@@ -323,6 +337,69 @@ def scene_case(gs):
     return {"scene": scene, "diff": diff, "mask_0.02": (diff > 0.02).astype(np.uint8)}
 
 
+VARIANTS = {
+    # name: (act_g, act_d, n_feat_layers, interm_non_act, use_feats)
+    "feats": ("relu", "lrelu", 2, False, True),
+    "non_act": ("relu", "lrelu", 2, True, True),
+    "non_act_allfeat": ("relu", "lrelu", 4, True, True),      # n_feat >= repeat: `main` is Identity
+    "relu_d": ("lrelu", "relu", 2, False, False),
+}
+
+
+def ref_key(k, interm_non_act):
+    """Oracle / default-layout key -> the reference module's key: with interm_non_act every layer is
+    Sequential(act, conv), so the convolution sits at index 1 (fixed_point_gan.py:109-111)."""
+    if interm_non_act:
+        return re.sub(r"^(features|main)\.(\d+)\.0\.", r"\1.\2.1.", k)
+    return k
+
+
+def run_variants(cfg):
+    """Optional configurations of the same step on the tiny config: the
+    reference modules built with the variant's constructor arguments; losses and gradients (under
+    the reference's own parameter names) stored; the oracle is checked against them on the way.
+    Inputs are synth_batch / synth_*_state of the tiny config (numpy-seeded, regenerated by the tests)."""
+    gs = O.synth_generator_state(cfg["g_conv_dim"], cfg["c_dim"], cfg["g_repeat"], cfg["bands"])
+    batch, alpha = O.synth_batch(cfg["batch"], cfg["size"], cfg["bands"])
+    t = {}
+    worst = 0.0
+    for name, (act_g, act_d, n_feat, ina, feats) in VARIANTS.items():
+        ds = O.synth_discriminator_state(cfg["size"], cfg["d_conv_dim"], cfg["c_dim"], cfg["d_repeat"], cfg["bands"],
+                                         n_feature_layers=n_feat)
+        rds = {ref_key(k, ina): v for k, v in ds.items()}
+        mk = lambda: ref_modules(gs, rds, cfg, act_g, act_d, n_feat, ina)   # noqa: E731
+        G, D = mk()
+        with torch.no_grad():
+            r_src, r_cls, r_feat = D(batch[0])
+        # (the reference returns the feature tensor as later in-place activations left it)
+        t[f"{name}.D_feat"] = r_feat[0].numpy().copy()
+        t[f"{name}.D_src"] = r_src.numpy()
+        G, D = mk()
+        _, dl, dg = ref_d_step(G, D, batch, alpha)
+        G, D = mk()
+        _, gl, gg = ref_g_step(G, D, batch, use_feats=feats)
+        _, odl, odg = O.d_step(gs, ds, batch, alpha, act_g=act_g, act_d=act_d, new_stats={}, interm_non_act=ina)
+        _, ogl, ogg = O.g_step(gs, ds, batch, act_g=act_g, act_d=act_d, new_stats={}, use_feats=feats,
+                               interm_non_act=ina)
+        with torch.no_grad():
+            o_src, _, o_feat = O.discriminator_forward(ds, batch[0], act_d, ina)
+        worst = max(worst, check(name + " D feat", o_feat[0], r_feat[0], 2e-6), check(name + " D src", o_src, r_src, 2e-6))
+        for k in dl:
+            worst = max(worst, check(f"{name} {k}", odl[k], dl[k], 1e-5))
+            t[f"{name}.dloss.{k}"] = dl[k].numpy()
+        for k in gl:
+            worst = max(worst, check(f"{name} {k}", ogl[k], gl[k], 1e-5))
+            t[f"{name}.gloss.{k}"] = gl[k].numpy()
+        for k in odg:
+            worst = max(worst, check(f"{name} dD/{k}", odg[k], dg[ref_key(k, ina)], 2e-3))
+            t[f"{name}.dgrad.{ref_key(k, ina)}"] = dg[ref_key(k, ina)].numpy()
+        for k in gg:
+            worst = max(worst, check(f"{name} dG/{k}", ogg[k], gg[k], 2e-3))
+            t[f"{name}.ggrad.{k}"] = gg[k].numpy()
+        print(f"variant {name}: oracle vs reference worst rel-err so far {worst:.2e}")
+    return t
+
+
 TINY = dict(batch=2, size=32, bands=10, c_dim=1, g_conv_dim=8, d_conv_dim=8, g_repeat=2, d_repeat=3)
 SMALL = dict(batch=3, size=64, bands=10, c_dim=1, g_conv_dim=16, d_conv_dim=16, g_repeat=3, d_repeat=5)
 FULL = dict(batch=16, size=128, bands=10, c_dim=1, g_conv_dim=64, d_conv_dim=64, g_repeat=6, d_repeat=6)
@@ -331,9 +408,13 @@ FULL = dict(batch=16, size=128, bands=10, c_dim=1, g_conv_dim=64, d_conv_dim=64,
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="also the full-size baseline config (scalars only)")
+    ap.add_argument("--variants", action="store_true", help="only tests/golden/tiny_variants.npz")
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
+    if args.variants:
+        np.savez_compressed(os.path.join(GOLD, "tiny_variants.npz"), **run_variants(TINY))
+        return
 
     r = run_config(TINY, True)
     np.savez_compressed(os.path.join(GOLD, "tiny_step.npz"), **r["tensors"])

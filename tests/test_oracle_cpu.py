@@ -123,3 +123,35 @@ def test_full_size_fixture_is_pinned():
     sc = json.load(open(os.path.join(GOLD, "full_scalars.json")))
     assert sc["cfg"]["batch"] == 16 and sc["cfg"]["size"] == 128
     assert sc["oracle_fp64_vs_reference_fp64_worst_relerr"] <= 1e-9
+
+
+def test_oracle_variants_match_reference_fixtures():
+    """use_feats / interm_non_act / ReLU discriminator: the oracle against
+    the reference-generated tests/golden/tiny_variants.npz (make_golden.py --variants)."""
+    import re
+    import pytest
+    variants = {"feats": ("relu", "lrelu", 2, False, True), "non_act": ("relu", "lrelu", 2, True, True),
+                "non_act_allfeat": ("relu", "lrelu", 4, True, True), "relu_d": ("lrelu", "relu", 2, False, False)}
+    z, sc, gs, _, _ = load_tiny()
+    cfg = sc["cfg"]
+    v = np.load(os.path.join(GOLD, "tiny_variants.npz"))
+    batch, alpha = O.synth_batch(cfg["batch"], cfg["size"], cfg["bands"])
+    for name, (act_g, act_d, n_feat, ina, feats) in variants.items():
+        ds = O.synth_discriminator_state(cfg["size"], cfg["d_conv_dim"], cfg["c_dim"], cfg["d_repeat"], cfg["bands"],
+                                         n_feature_layers=n_feat)
+        rk = (lambda k: re.sub(r"^(features|main)\.(\d+)\.0\.", r"\1.\2.1.", k)) if ina else (lambda k: k)
+        with torch.no_grad():
+            src, _, feat = O.discriminator_forward(ds, batch[0], act_d, ina)
+        assert relerr(src, torch.from_numpy(v[f"{name}.D_src"])) <= 2e-6
+        assert relerr(feat[0], torch.from_numpy(v[f"{name}.D_feat"])) <= 2e-6
+        _, dl, dg = O.d_step(gs, ds, batch, alpha, act_g=act_g, act_d=act_d, new_stats={}, interm_non_act=ina)
+        for k, t in dl.items():
+            assert float(t) == pytest.approx(float(v[f"{name}.dloss.{k}"]), rel=1e-5, abs=1e-5)
+        for k, g in dg.items():
+            assert relerr(g, torch.from_numpy(v[f"{name}.dgrad.{rk(k)}"])) <= 1e-4, (name, k)
+        _, gl, gg = O.g_step(gs, ds, batch, act_g=act_g, act_d=act_d, new_stats={}, use_feats=feats, interm_non_act=ina)
+        assert len(gl) == (10 if feats else 7)
+        for k, t in gl.items():
+            assert float(t) == pytest.approx(float(v[f"{name}.gloss.{k}"]), rel=1e-5, abs=1e-5)
+        for k, g in gg.items():
+            assert relerr(g, torch.from_numpy(v[f"{name}.ggrad.{k}"])) <= 1e-4, (name, k)

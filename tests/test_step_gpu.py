@@ -304,3 +304,79 @@ def test_bf16_variant_losses(dev, tiny):
         ref = torch.from_numpy(z["ggrad." + name]).to(dev)
         cos = float((p.grad * ref).sum() / (p.grad.norm() * ref.norm() + 1e-30))
         assert cos > 0.8, (name, cos)
+
+
+# --------------------------------------------------------------------------- #
+# optional configurations: use_feats, interm_non_act, ReLU discriminator
+# --------------------------------------------------------------------------- #
+VARIANTS = {
+    # name: (act_g, act_d, n_feat_layers, interm_non_act, use_feats) -- oracle/make_golden.py VARIANTS
+    "feats": ("relu", "lrelu", 2, False, True),
+    "non_act": ("relu", "lrelu", 2, True, True),
+    "non_act_allfeat": ("relu", "lrelu", 4, True, True),
+    "relu_d": ("lrelu", "relu", 2, False, False),
+}
+
+
+def build_variant(name, cfg, dev):
+    import re
+    from fcd_amd import FCDSolver
+    from oracle import fcd_oracle as O
+    act_g, act_d, n_feat, ina, feats = VARIANTS[name]
+    s = FCDSolver(None, c_dim=cfg["c_dim"], image_size=cfg["size"], g_conv_dim=cfg["g_conv_dim"],
+                  d_conv_dim=cfg["d_conv_dim"], g_repeat_num=cfg["g_repeat"], d_repeat_num=cfg["d_repeat"],
+                  num_channels=cfg["bands"], batch_size=cfg["batch"], act_G=act_g, act_D=act_d, n_feat_layers=n_feat,
+                  interm_non_act=ina, use_feats=feats)
+    gs = O.synth_generator_state(cfg["g_conv_dim"], cfg["c_dim"], cfg["g_repeat"], cfg["bands"])
+    ds = O.synth_discriminator_state(cfg["size"], cfg["d_conv_dim"], cfg["c_dim"], cfg["d_repeat"], cfg["bands"],
+                                     n_feature_layers=n_feat)
+    if ina:     # the reference's keys: Sequential(act, conv) puts the convolution at index 1
+        ds = {re.sub(r"^(features|main)\.(\d+)\.0\.", r"\1.\2.1.", k): v for k, v in ds.items()}
+    s.G.load_state_dict(gs)
+    s.D.load_state_dict(ds)          # strict: the key layout must be the reference's
+    return s.to(dev)
+
+
+@pytest.mark.parametrize("name", list(VARIANTS))
+@pytest.mark.parametrize("prec", ["fp32", "fp32x3"])
+def test_variant_steps(dev, tiny, name, prec):
+    from oracle import fcd_oracle as O
+    z, sc = tiny
+    v = np.load(os.path.join(GOLD, "tiny_variants.npz"))
+    cfg = sc["cfg"]
+    batch, alpha = O.synth_batch(cfg["batch"], cfg["size"], cfg["bands"])
+    b = tuple(t.to(dev) for t in batch)
+    s = build_variant(name, cfg, dev)
+    s.set_precision(prec)
+    with torch.no_grad():
+        src, _, feat = s.D(b[0])
+    assert relerr(src, torch.from_numpy(v[f"{name}.D_src"])) <= TOL
+    assert relerr(feat[0], torch.from_numpy(v[f"{name}.D_feat"])) <= TOL
+    # D step
+    s.alpha_override = alpha
+    s.G.requires_grad_(False)
+    s.training_step(b, 0, 0).backward()
+    for k in [k for k in v.files if k.startswith(f"{name}.dloss.")]:
+        ref = float(v[k])
+        assert abs(float(s.loss_dict[k.split(".dloss.")[1]]) - ref) <= TOL * max(1.0, abs(ref)), k
+    worst = 0.0
+    for pname, p in s.D.named_parameters():
+        e = relerr(p.grad if p.grad is not None else torch.zeros_like(p), torch.from_numpy(v[f"{name}.dgrad.{pname}"]))
+        worst = max(worst, e)
+        assert e <= TOL, (name, pname, e)
+    # G step (fresh modules: running statistics as in the fixture)
+    s = build_variant(name, cfg, dev)
+    s.set_precision(prec)
+    s.D.requires_grad_(False)
+    s.global_step = s.n_critic - 1
+    s.training_step(b, 0, 1).backward()
+    gl = [k for k in v.files if k.startswith(f"{name}.gloss.")]
+    assert len(gl) == (10 if VARIANTS[name][4] else 7)
+    for k in gl:
+        ref = float(v[k])
+        assert abs(float(s.loss_dict[k.split(".gloss.")[1]]) - ref) <= TOL * max(1.0, abs(ref)), k
+    for pname, p in s.G.named_parameters():
+        e = relerr(p.grad, torch.from_numpy(v[f"{name}.ggrad.{pname}"]))
+        worst = max(worst, e)
+        assert e <= TOL, (name, pname, e)
+    print(f"variant {name} [{prec}] worst grad rel-err {worst:.2e}")
