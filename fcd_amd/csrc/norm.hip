@@ -44,6 +44,27 @@ __device__ __forceinline__ float in_forward_value(float z, float mu, float rs, f
   return (z - mu) * rs * ga + be;
 }
 
+// Activation after the norm.  act_slope in [0, 1] is the leaky family (0 = ReLU, 0.01 = LeakyReLU,
+// 1 = none); FCD_ACT_SILU / FCD_ACT_MISH (fcd_hip.h) select nn.SiLU / nn.Mish
+// (fixed_point_gan.py:13-16), whose derivative needs the pre-activation value: the backward
+// recomputes it from z (beta must be given).  Formulas as in torch: silu = u * sigmoid(u);
+// mish = u * tanh(softplus(u)), softplus(u) = u for u > 20.
+__device__ __forceinline__ float act_value(float u, float code) {
+  if (code <= 1.f) return u > 0.f ? u : u * code;
+  if (code == FCD_ACT_SILU) return u / (1.f + expf(-u));
+  const float sp = u > 20.f ? u : log1pf(expf(u));
+  return u * tanhf(sp);
+}
+
+__device__ __forceinline__ float act_slope_at(float u, float code) {
+  if (code <= 1.f) return u > 0.f ? 1.f : code;
+  const float sg = 1.f / (1.f + expf(-u));
+  if (code == FCD_ACT_SILU) return sg * (1.f + u * (1.f - sg));
+  const float sp = u > 20.f ? u : log1pf(expf(u));
+  const float t = tanhf(sp);
+  return t + u * sg * (1.f - t * t);
+}
+
 // partial[n][chunk][c][2] (double)
 template <int MODE>
 __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restrict__ x0, const float* __restrict__ x1,
@@ -104,7 +125,7 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restric
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float g1 = av[e] * (yv[e] > 0.f ? 1.f : act_slope);
+          const float g1 = av[e] * act_slope_at(yv[e], act_slope);
           s0[e] += g1;
           s1[e] += g1 * ((zv[e] - mu[e]) * rs[e]);
         }
@@ -210,10 +231,10 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const float* __restrict__
     o.y = in_forward_value(zv.y, mu.y, rs.y, ga.y, be.y);
     o.z = in_forward_value(zv.z, mu.z, rs.z, ga.z, be.z);
     o.w = in_forward_value(zv.w, mu.w, rs.w, ga.w, be.w);
-    o.x = o.x > 0.f ? o.x : o.x * act_slope;
-    o.y = o.y > 0.f ? o.y : o.y * act_slope;
-    o.z = o.z > 0.f ? o.z : o.z * act_slope;
-    o.w = o.w > 0.f ? o.w : o.w * act_slope;
+    o.x = act_value(o.x, act_slope);
+    o.y = act_value(o.y, act_slope);
+    o.z = act_value(o.z, act_slope);
+    o.w = act_value(o.w, act_slope);
     if (res) {
       const float4 r = *reinterpret_cast<const float4*>(res + idx * 4);
       o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
@@ -268,7 +289,7 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const float* __restri
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       if (recompute) yy[e] = in_forward_value(zz[e], mu[e], rs[e], ga[e], be[e]);
-      const float g1 = gv[e] * (yy[e] > 0.f ? 1.f : act_slope);
+      const float g1 = gv[e] * act_slope_at(yy[e], act_slope);
       if (use_running) {
         o[e] = k0[e] * g1;
       } else {
@@ -371,6 +392,8 @@ extern "C" int fcd_instnorm_apply(const float* z, const float* mean, const float
   int rc = check_nhwc("instnorm_apply", N, HW, C);
   if (rc) return rc;
   FCD_REQUIRE(z && mean && rstd && gamma && beta && y, "instnorm_apply: null tensor");
+  FCD_REQUIRE((act_slope >= 0.f && act_slope <= 1.f) || act_slope == FCD_ACT_SILU || act_slope == FCD_ACT_MISH,
+              "instnorm_apply: act_slope %g is neither a slope in [0,1] nor an activation code", act_slope);
   const long total4 = (long)N * HW * (C / 4);
   const int blocks = (int)std::min<long>(fcd_cdiv(total4, 256), 8192);
   hipLaunchKernelGGL(in_apply_kernel, dim3(blocks), dim3(256), 0, fcd_stream(stream), z, mean, rstd, gamma, beta,
@@ -387,6 +410,9 @@ extern "C" int fcd_instnorm_bwd(const float* gy, const float* y, const float* z,
   if (rc) return rc;
   FCD_REQUIRE(gy && z && mean && rstd && gamma && dz, "instnorm_bwd: null tensor");
   FCD_REQUIRE(y || beta || act_slope == 1.f, "instnorm_bwd: the activation mask needs y or beta");
+  FCD_REQUIRE(act_slope <= 1.f || beta, "instnorm_bwd: SiLU / Mish need beta (their slope is recomputed from z)");
+  FCD_REQUIRE((act_slope >= 0.f && act_slope <= 1.f) || act_slope == FCD_ACT_SILU || act_slope == FCD_ACT_MISH,
+              "instnorm_bwd: act_slope %g is neither a slope in [0,1] nor an activation code", act_slope);
   const size_t pb = partial_bytes(N, HW, C);
   if (!workspace || workspace_bytes < pb + (size_t)N * C * 2 * sizeof(float)) {
     fcd_set_error("instnorm_bwd: workspace too small");

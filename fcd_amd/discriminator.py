@@ -72,6 +72,10 @@ class Discriminator(nn.Module):
         # relu / lrelu: the backward masks come from the sign of the stored output (y > 0 <=> z > 0;
         # at z == 0 both torch and this path take the negative-side slope)
         self.slope = _act_slope(activation)
+        if self.slope > 1.0:
+            # SiLU / Mish in D need the stored pre-activations and a second-derivative term in the
+            # gradient penalty's double backward: not built
+            raise NotImplementedError(f"Discriminator activation {activation!r} has no HIP path (relu / lrelu only)")
         self.interm_non_act = bool(interm_non_act)
         self.image_size, self.c_dim, self.num_channels = image_size, c_dim, num_channels
         self.precision = L.PREC_F32

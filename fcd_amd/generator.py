@@ -31,7 +31,12 @@ def _act_slope(activation: str) -> float:
         return 0.0
     if activation == "lrelu":
         return ops.LRELU_SLOPE
-    # silu / mish (fixed_point_gan.py:13-16) are outside the hot path
+    # nn.SiLU / nn.Mish (fixed_point_gan.py:13-16): activation codes of the InstanceNorm kernels
+    # (generator only; the discriminator rejects them, see discriminator.py)
+    if activation == "silu":
+        return ops.ACT_SILU
+    if activation == "mish":
+        return ops.ACT_MISH
     raise NotImplementedError(f"activation {activation!r} has no HIP kernel")
 
 

@@ -16,6 +16,7 @@ from . import _lib as L
 from ._lib import ConvDesc, WgradDesc, check, ptr, stream
 
 LRELU_SLOPE = 0.01
+ACT_SILU, ACT_MISH = 2.0, 3.0   # FCD_ACT_SILU / FCD_ACT_MISH (fcd_hip.h)
 IN_EPS = 1e-5
 IN_MOMENTUM = 0.1
 

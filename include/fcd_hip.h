@@ -43,6 +43,10 @@ extern "C" {
 #define FCD_PREC_BF16X3 2 /* each fp32 operand split into three bf16 pieces in registers, six bf16 MFMAs
                              per product group, fp32 accumulate: fp32-faithful at the bf16 matrix rate */
 
+/* activation codes accepted where an InstanceNorm entry point takes `act_slope` (values outside [0,1]) */
+#define FCD_ACT_SILU 2.0f
+#define FCD_ACT_MISH 3.0f
+
 const char* fcd_last_error(void);
 int fcd_abi_version(void);
 /* Checks that `device` is a gfx950 part and makes it current. */
@@ -161,7 +165,9 @@ int fcd_instnorm_stats_from_running(const float* running_mean, const float* runn
 int fcd_instnorm_update_running(float* running_mean, float* running_var, const float* mean,
                                 const float* var_unbiased, int N, int C, float momentum,
                                 void* stream);
-/* y = act((z-mean)*rstd*gamma + beta) (+ residual); relu: act_slope 0, none: 1. */
+/* y = act((z-mean)*rstd*gamma + beta) (+ residual); relu: act_slope 0, lrelu: 0.01, none: 1;
+ * FCD_ACT_SILU / FCD_ACT_MISH in place of a slope select nn.SiLU / nn.Mish
+ * (fixed_point_gan.py:13-16; instnorm_apply / instnorm_bwd only: the generator's activations). */
 int fcd_instnorm_apply(const float* z, const float* mean, const float* rstd, const float* gamma,
                        const float* beta, const float* residual, float* y, int N, int HW, int C,
                        float act_slope, void* stream);

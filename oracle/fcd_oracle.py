@@ -53,7 +53,11 @@ def _act(name: str, t: Tensor) -> Tensor:
         return F.relu(t)
     if name == "lrelu":
         return F.leaky_relu(t, LRELU_SLOPE)
-    raise NotImplementedError(name)  # silu / mish: SURVEY section 8(f) rank 4
+    if name == "silu":
+        return F.silu(t)
+    if name == "mish":
+        return F.mish(t)
+    raise NotImplementedError(name)
 
 
 # --------------------------------------------------------------------------- #

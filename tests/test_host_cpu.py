@@ -93,8 +93,15 @@ def test_product_path_fails_loudly_on_cpu():
         G(torch.zeros(1, 10, 16, 16), torch.zeros(1, 1))
     with pytest.raises(RuntimeError, match="HIP path"):
         Discriminator(16, 8, 1, 2, 10)(torch.zeros(1, 10, 16, 16))
+    # options without a HIP path are rejected at construction, not silently emulated
     with pytest.raises(NotImplementedError):
-        Generator(8, 1, 1, 10, activation="mish")
+        Generator(8, 1, 1, 10, activation="gelu")
+    with pytest.raises(NotImplementedError):
+        Discriminator(16, 8, 1, 2, 10, activation="mish")
+    with pytest.raises(NotImplementedError):
+        Discriminator(16, 8, 1, 2, 10, use_attention=True)
+    # interm_non_act keeps the reference's key layout (Sequential(act, conv): conv at index 1)
+    assert "features.0.1.weight" in Discriminator(16, 8, 1, 2, 10, interm_non_act=True).state_dict()
 
 
 def test_no_oracle_import_in_product():

@@ -315,6 +315,8 @@ VARIANTS = {
     "non_act": ("relu", "lrelu", 2, True, True),
     "non_act_allfeat": ("relu", "lrelu", 4, True, True),
     "relu_d": ("lrelu", "relu", 2, False, False),
+    "silu_g": ("silu", "lrelu", 4, False, False),
+    "mish_g": ("mish", "lrelu", 4, False, True),
 }
 
 
