@@ -82,6 +82,9 @@ PROTOTYPES = {
     "fcd_nchw_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "fcd_nhwc_to_nchw": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "fcd_lrelu_bwd": (_I, [_P, _P, _P, _Z, _F, _P]),
+    "fcd_act_fwd": (_I, [_P, _P, _Z, _F, _P]),
+    "fcd_act_bwd": (_I, [_P, _P, _P, _Z, _F, _I, _P]),
+    "fcd_act_bwd2": (_I, [_P, _P, _P, _P, _P, _Z, _F, _P]),
     "fcd_colsum_workspace_bytes": (_Z, [_Z, _I]),
     "fcd_colsum": (_I, [_P, _P, _I, _Z, _I, _P, _Z, _P]),
     "fcd_reduce_workspace_bytes": (_Z, []),

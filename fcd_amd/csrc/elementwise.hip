@@ -96,6 +96,31 @@ __global__ __launch_bounds__(256) void lrelu_bwd_kernel(const float* __restrict_
     out[i] = g[i] * (y[i] > 0.f ? 1.f : slope);
 }
 
+// Smooth activations of the discriminator (SiLU / Mish), kept un-fused: a = act(z); first backward
+// g * act'(z); backward of that backward: u_out = ubar * act'(z), q = ubar * ga * act''(z).
+__global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ z, float* __restrict__ a, size_t n,
+                                                      float code) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) a[i] = act_value(z[i], code);
+}
+
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ g, const float* __restrict__ z,
+                                                      float* __restrict__ out, size_t n, float code, int accumulate) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float v = g[i] * act_slope_at(z[i], code);
+    out[i] = accumulate ? out[i] + v : v;
+  }
+}
+
+__global__ __launch_bounds__(256) void act_bwd2_kernel(const float* __restrict__ ubar, const float* __restrict__ ga,
+                                                       const float* __restrict__ z, float* __restrict__ u_out,
+                                                       float* __restrict__ q_out, size_t n, float code) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float ub = ubar[i], zz = z[i];
+    u_out[i] = ub * act_slope_at(zz, code);
+    q_out[i] = ub * ga[i] * act_curv_at(zz, code);
+  }
+}
+
 __global__ __launch_bounds__(256) void fill_scaled_kernel(float* __restrict__ out, size_t n, float scale,
                                                           const float* __restrict__ gscale) {
   const float v = scale * gscale[0];
@@ -399,6 +424,29 @@ extern "C" int fcd_lrelu_bwd(const float* g, const float* y, float* out, size_t 
   FCD_REQUIRE(g && y && out && n > 0, "lrelu_bwd: bad arguments");
   hipLaunchKernelGGL(lrelu_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, fcd_stream(stream), g, y, out, n, slope);
   return fcd_check_launch("lrelu_bwd");
+}
+
+static int act_code_ok(float code) {
+  return (code >= 0.f && code <= 1.f) || code == FCD_ACT_SILU || code == FCD_ACT_MISH;
+}
+
+extern "C" int fcd_act_fwd(const float* z, float* a, size_t n, float act, void* stream) {
+  FCD_REQUIRE(z && a && n > 0 && act_code_ok(act), "act_fwd: bad arguments");
+  hipLaunchKernelGGL(act_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, fcd_stream(stream), z, a, n, act);
+  return fcd_check_launch("act_fwd");
+}
+
+extern "C" int fcd_act_bwd(const float* g, const float* z, float* out, size_t n, float act, int accumulate, void* stream) {
+  FCD_REQUIRE(g && z && out && n > 0 && act_code_ok(act), "act_bwd: bad arguments");
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, fcd_stream(stream), g, z, out, n, act, accumulate);
+  return fcd_check_launch("act_bwd");
+}
+
+extern "C" int fcd_act_bwd2(const float* ubar, const float* ga, const float* z, float* u_out, float* q_out, size_t n,
+                            float act, void* stream) {
+  FCD_REQUIRE(ubar && ga && z && u_out && q_out && n > 0 && act_code_ok(act), "act_bwd2: bad arguments");
+  hipLaunchKernelGGL(act_bwd2_kernel, dim3(grid_for(n)), dim3(256), 0, fcd_stream(stream), ubar, ga, z, u_out, q_out, n, act);
+  return fcd_check_launch("act_bwd2");
 }
 
 extern "C" int fcd_fill_scaled(float* out, size_t n, float scale, const float* gscale, void* stream) {

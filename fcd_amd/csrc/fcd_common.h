@@ -67,3 +67,33 @@ __device__ __forceinline__ double block_sum_256_d(double v, double* smem4) {
   __syncthreads();
   return smem4[0] + smem4[1] + smem4[2] + smem4[3];
 }
+
+// Activations.  A code in [0, 1] is the leaky family (0 = ReLU, 0.01 = LeakyReLU, 1 = none);
+// FCD_ACT_SILU / FCD_ACT_MISH (fcd_hip.h) select nn.SiLU / nn.Mish (fixed_point_gan.py:13-16).
+// Formulas as in torch: silu = u * sigmoid(u); mish = u * tanh(softplus(u)), softplus(u) = u for u > 20.
+// act_slope_at / act_curv_at are the first / second derivative at the pre-activation value u.
+__device__ __forceinline__ float act_value(float u, float code) {
+  if (code <= 1.f) return u > 0.f ? u : u * code;
+  if (code == FCD_ACT_SILU) return u / (1.f + expf(-u));
+  const float sp = u > 20.f ? u : log1pf(expf(u));
+  return u * tanhf(sp);
+}
+
+__device__ __forceinline__ float act_slope_at(float u, float code) {
+  if (code <= 1.f) return u > 0.f ? 1.f : code;
+  const float sg = 1.f / (1.f + expf(-u));
+  if (code == FCD_ACT_SILU) return sg * (1.f + u * (1.f - sg));
+  const float sp = u > 20.f ? u : log1pf(expf(u));
+  const float t = tanhf(sp);
+  return t + u * sg * (1.f - t * t);
+}
+
+__device__ __forceinline__ float act_curv_at(float u, float code) {
+  if (code <= 1.f) return 0.f;
+  const float sg = 1.f / (1.f + expf(-u));
+  if (code == FCD_ACT_SILU) return sg * (1.f - sg) * (2.f + u * (1.f - 2.f * sg));
+  const float sp = u > 20.f ? u : log1pf(expf(u));
+  const float t = tanhf(sp);
+  const float w = (1.f - t * t) * sg;          // d tanh(softplus(u)) / du
+  return 2.f * w + u * w * ((1.f - sg) - 2.f * t * sg);
+}

@@ -44,27 +44,7 @@ __device__ __forceinline__ float in_forward_value(float z, float mu, float rs, f
   return (z - mu) * rs * ga + be;
 }
 
-// Activation after the norm.  act_slope in [0, 1] is the leaky family (0 = ReLU, 0.01 = LeakyReLU,
-// 1 = none); FCD_ACT_SILU / FCD_ACT_MISH (fcd_hip.h) select nn.SiLU / nn.Mish
-// (fixed_point_gan.py:13-16), whose derivative needs the pre-activation value: the backward
-// recomputes it from z (beta must be given).  Formulas as in torch: silu = u * sigmoid(u);
-// mish = u * tanh(softplus(u)), softplus(u) = u for u > 20.
-__device__ __forceinline__ float act_value(float u, float code) {
-  if (code <= 1.f) return u > 0.f ? u : u * code;
-  if (code == FCD_ACT_SILU) return u / (1.f + expf(-u));
-  const float sp = u > 20.f ? u : log1pf(expf(u));
-  return u * tanhf(sp);
-}
-
-__device__ __forceinline__ float act_slope_at(float u, float code) {
-  if (code <= 1.f) return u > 0.f ? 1.f : code;
-  const float sg = 1.f / (1.f + expf(-u));
-  if (code == FCD_ACT_SILU) return sg * (1.f + u * (1.f - sg));
-  const float sp = u > 20.f ? u : log1pf(expf(u));
-  const float t = tanhf(sp);
-  return t + u * sg * (1.f - t * t);
-}
-
+// act_value / act_slope_at: fcd_common.h
 // partial[n][chunk][c][2] (double)
 template <int MODE>
 __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restrict__ x0, const float* __restrict__ x1,

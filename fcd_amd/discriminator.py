@@ -71,11 +71,10 @@ class Discriminator(nn.Module):
             raise NotImplementedError("use_attention has no HIP path")
         # relu / lrelu: the backward masks come from the sign of the stored output (y > 0 <=> z > 0;
         # at z == 0 both torch and this path take the negative-side slope)
+        # silu / mish: un-fused activations on stored pre-activations and a second-derivative sweep
+        # in the double backward (_SmoothDiscriminatorFn below)
         self.slope = _act_slope(activation)
-        if self.slope > 1.0:
-            # SiLU / Mish in D need the stored pre-activations and a second-derivative term in the
-            # gradient penalty's double backward: not built
-            raise NotImplementedError(f"Discriminator activation {activation!r} has no HIP path (relu / lrelu only)")
+        self.smooth = self.slope > 1.0
         self.interm_non_act = bool(interm_non_act)
         self.image_size, self.c_dim, self.num_channels = image_size, c_dim, num_channels
         self.precision = L.PREC_F32
@@ -118,7 +117,8 @@ class Discriminator(nn.Module):
         if not x.is_cuda:
             raise RuntimeError("fcd_amd.Discriminator runs on the MI355X HIP path only")
         x = x.contiguous().float()
-        out_src, out_cls, feat = _DiscriminatorFn.apply(self, x, *self._flat_params())
+        fn = _SmoothDiscriminatorFn if self.smooth else _DiscriminatorFn
+        out_src, out_cls, feat = fn.apply(self, x, *self._flat_params())
         return out_src, out_cls.view(out_cls.size(0), out_cls.size(1)), [feat]
 
 
@@ -276,3 +276,197 @@ class _DBackwardFn(torch.autograd.Function):
         # d/d g_src, d/d g_cls (linear) are not needed by the GP: grad_outputs is a constant
         ctx.gzs = None
         return (None,) * 8 + tuple(out)
+
+
+# --------------------------------------------------------------------------- #
+# SiLU / Mish discriminator (fixed_point_gan.py:13-16)
+# --------------------------------------------------------------------------- #
+# With z_l = W_l * a_{l-1} + b_l, a_l = act(z_l), the first backward is
+#     gz_l = ga_l . act'(z_l),   ga_{l-1} = W_l^T gz_l,   gx = ga_{-1}.
+# act'' != 0, so the backward of that backward (the gradient penalty's) has, besides the forward
+# convolutions of the incoming cotangent u (ubar_l = W_l u_{l-1}, u_l = ubar_l . act'(z_l)) and the
+# weight gradients gz_l (x) u_{l-1}, a second sweep: q_l = ubar_l . ga_l . act''(z_l) is a cotangent
+# of z_l itself and runs down the forward network like an ordinary backward pass
+#     r_l = q_l + (W_{l+1}^T r_{l+1}) . act'(z_l),   dW_l += r_l (x) a_{l-1},   db_l += sum r_l.
+# The activations are separate elementwise launches here (fcd_act_fwd / _bwd / _bwd2): the option is
+# off by default and D is 7 % of the step.
+class _SmoothDiscriminatorFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mod: Discriminator, x, *params):
+        L.require_gpu_tensor(x, "x")
+        n, ch, h, w = x.shape
+        if ch != mod.num_channels:
+            raise RuntimeError(f"Discriminator: expected {mod.num_channels} bands")
+        prec = mod.precision
+        acts = [ops.nchw_to_nhwc(x, mod._geoms[0].IP)]
+        zs = []
+        for li, (cv, g) in enumerate(zip(mod._convs, mod._geoms)):
+            a = acts[-1]
+            d = g.fwd_desc(n, a.shape[1], a.shape[2], precision=prec)
+            z = ops.conv_gather(d, a, cv.operand("fwd", g, d), bias=params[2 * li + 1])
+            zs.append(z)
+            acts.append(z if mod._slopes[li] == 1.0 else ops.act_fwd(z, mod._slopes[li]))
+        top = acts[-1]
+        if top.shape[1] < mod._g2.k or top.shape[2] < mod._g2.k:
+            raise RuntimeError("Discriminator: input smaller than image_size")
+        out_src = ops.head_fwd(top, mod.conv1.packed("fwd", mod._g1), 1, 3, 1)
+        out_cls = ops.head_fwd(top, mod.conv2.packed("fwd", mod._g2), mod.c_dim, mod._g2.k, 0)
+        feat = ops.nhwc_to_nchw(acts[mod._n_feat], mod._geoms[mod._n_feat - 1].O)
+        ctx.mod, ctx.acts, ctx.zs, ctx.prec = mod, acts, zs, prec
+        ctx.set_materialize_grads(False)
+        return out_src, out_cls, feat
+
+    @staticmethod
+    def backward(ctx, g_src, g_cls, g_feat):
+        mod = ctx.mod
+        needs = ctx.needs_input_grad
+        want_params = any(needs[2:]) and not getattr(_state, "input_only", False)
+        outs = _SmoothDBackwardFn.apply(mod, ctx.acts, ctx.zs, ctx.prec, needs[1], want_params, g_src, g_cls, g_feat,
+                                        *mod._flat_params())
+        res = [None, outs[0] if needs[1] else None]
+        for i, gp in enumerate(outs[1:]):
+            res.append(gp if (want_params and needs[2 + i]) else None)
+        return tuple(res)
+
+
+def _add_grad(slot, new):
+    return new if slot is None else slot + new
+
+
+class _SmoothDBackwardFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mod: Discriminator, acts, zs, prec, want_x, want_params, g_src, g_cls, g_feat, *params):
+        n = acts[0].shape[0]
+        codes = mod._slopes
+        prec_w = prec if mod.wgrad_precision is None else mod.wgrad_precision
+        top = acts[-1]
+        nl = len(mod._convs)
+        grads: List[Optional[torch.Tensor]] = [None] * (2 * nl + 2)
+        ga = torch.empty_like(top)            # cotangent of a_top (no activation factor yet)
+        first = True
+        if g_src is not None:
+            g_src = g_src.contiguous()
+            ops.head_dgrad(g_src, mod.conv1.packed("fwd", mod._g1), ga, top, 1.0, False, 3, 1)
+            first = False
+            if want_params:
+                sink = grad_sink(mod.conv1.weight, True)
+                dw = ops.head_wgrad(g_src, top, mod._g1.I, 3, 1, dw=sink, accumulate=sink is not None)
+                grads[2 * nl] = None if sink is not None else dw
+        if g_cls is not None:
+            g_cls4 = g_cls.contiguous().view(n, mod.c_dim, 1, 1)
+            ops.head_dgrad(g_cls4, mod.conv2.packed("fwd", mod._g2), ga, top, 1.0, not first, mod._g2.k, 0)
+            first = False
+            if want_params:
+                sink = grad_sink(mod.conv2.weight, True)
+                dw = ops.head_wgrad(g_cls4, top, mod._g2.I, mod._g2.k, 0, dw=sink, accumulate=sink is not None)
+                grads[2 * nl + 1] = None if sink is not None else dw
+        if first:
+            ga.zero_()
+        gas, gzs = [None] * nl, [None] * nl
+        gx = None
+        for li in range(nl - 1, -1, -1):
+            if g_feat is not None and li == mod._n_feat - 1:
+                ga = ga + ops.nchw_to_nhwc(g_feat.contiguous(), acts[li + 1].shape[3])
+            gas[li] = ga
+            gz = ga if codes[li] == 1.0 else ops.act_bwd(ga, zs[li], codes[li])
+            gzs[li] = gz
+            g = mod._geoms[li]
+            a_in = acts[li]
+            if want_params:
+                cv = mod._convs[li]
+                sink = grad_sink(cv.weight, True)
+                wd = g.wgrad_desc(n, a_in.shape[1], a_in.shape[2], precision=prec_w, accumulate=sink is not None)
+                dw = ops.conv_wgrad(wd, gz, a_in, dw=sink)
+                grads[2 * li] = None if sink is not None else dw
+                bsink = grad_sink(cv.bias, gz.shape[3] == g.O)
+                bs = ops.colsum(gz.numel() // gz.shape[3], gz, gz.shape[3], out=bsink, accumulate=bsink is not None)
+                if bsink is None:
+                    grads[2 * li + 1] = bs if gz.shape[3] == g.O else bs[: g.O].contiguous()
+            if li == 0 and not want_x:
+                break
+            d = g.adj_desc(n, gz.shape[1], gz.shape[2], precision=prec)
+            ga = ops.conv_gather(d, gz, mod._convs[li].operand("adj", g, d))
+            if li == 0:
+                gx = ops.nhwc_to_nchw(ga, mod.num_channels)
+        ctx.mod, ctx.acts, ctx.zs, ctx.prec, ctx.gas, ctx.gzs = mod, acts, zs, prec, gas, gzs
+        ctx.g_src, ctx.g_cls = g_src, g_cls
+        ctx.set_materialize_grads(False)
+        if gx is None:
+            gx = torch.zeros((n, mod.num_channels) + tuple(acts[0].shape[1:3]), device=top.device)
+        return (gx,) + tuple(grads)
+
+    @staticmethod
+    def backward(ctx, gg_x, *gg_params):
+        if any(t is not None for t in gg_params):
+            raise NotImplementedError("differentiating through D's parameter gradients is not supported")
+        mod, acts, zs, prec, gas, gzs = ctx.mod, ctx.acts, ctx.zs, ctx.prec, ctx.gas, ctx.gzs
+        prec_w = prec if mod.wgrad_precision is None else mod.wgrad_precision
+        codes = mod._slopes
+        nl = len(mod._convs)
+        # inputs: mod, acts, zs, prec, want_x, want_params, g_src, g_cls, g_feat, *params
+        needs = ctx.needs_input_grad[9:]
+        out: List[Optional[torch.Tensor]] = [None] * len(needs)
+        if gg_x is None:
+            return (None,) * 9 + tuple(out)
+        n = acts[0].shape[0]
+
+        def add_w(li, gz, a):
+            sink = grad_sink(mod._convs[li].weight, True)
+            g = mod._geoms[li]
+            wd = g.wgrad_desc(n, a.shape[1], a.shape[2], precision=prec_w, accumulate=sink is not None)
+            dw = ops.conv_wgrad(wd, gz, a, dw=sink)
+            if sink is None:
+                out[2 * li] = _add_grad(out[2 * li], dw)
+
+        # sweep 1 (up): cotangents of the first backward's gz_l / ga_l
+        u = ops.nchw_to_nhwc(gg_x.contiguous(), mod._geoms[0].IP)
+        qs = [None] * nl
+        for li in range(nl):
+            g = mod._geoms[li]
+            if needs[2 * li]:
+                add_w(li, gzs[li], u)
+            d = g.fwd_desc(n, u.shape[1], u.shape[2], precision=prec)
+            ubar = ops.conv_gather(d, u, mod._convs[li].operand("fwd", g, d))
+            if codes[li] == 1.0:
+                u = ubar
+            else:
+                u, qs[li] = ops.act_bwd2(ubar, gas[li], zs[li], codes[li])
+        if needs[2 * nl] and ctx.g_src is not None:
+            sink = grad_sink(mod.conv1.weight, True)
+            dw = ops.head_wgrad(ctx.g_src, u, mod._g1.I, 3, 1, dw=sink, accumulate=sink is not None)
+            out[2 * nl] = None if sink is not None else dw
+        if needs[2 * nl + 1] and ctx.g_cls is not None:
+            sink = grad_sink(mod.conv2.weight, True)
+            dw = ops.head_wgrad(ctx.g_cls.contiguous().view(n, mod.c_dim, 1, 1), u, mod._g2.I, mod._g2.k, 0, dw=sink,
+                                accumulate=sink is not None)
+            out[2 * nl + 1] = None if sink is not None else dw
+        # sweep 2 (down): the cotangents q_l of the pre-activations through the forward network
+        r = None                      # cotangent of a_l arriving from the layer above
+        for li in range(nl - 1, -1, -1):
+            if r is None:
+                r = qs[li]
+            elif codes[li] == 1.0:
+                pass                  # a_l == z_l
+            elif qs[li] is not None:
+                r = ops.act_bwd(r, zs[li], codes[li], out=qs[li], accumulate=True)
+            else:
+                r = ops.act_bwd(r, zs[li], codes[li])
+            if r is None:
+                continue
+            g = mod._geoms[li]
+            if needs[2 * li]:
+                add_w(li, r, acts[li])
+            if needs[2 * li + 1]:
+                cv = mod._convs[li]
+                bsink = grad_sink(cv.bias, r.shape[3] == g.O)
+                bs = ops.colsum(r.numel() // r.shape[3], r, r.shape[3], out=bsink, accumulate=bsink is not None)
+                if bsink is None:
+                    out[2 * li + 1] = bs if r.shape[3] == g.O else bs[: g.O].contiguous()
+            if li > 0:
+                d = g.adj_desc(n, r.shape[1], r.shape[2], precision=prec)
+                r = ops.conv_gather(d, r, mod._convs[li].operand("adj", g, d))
+        for li in range(nl):          # parameters that received nothing still get a defined gradient
+            if needs[2 * li + 1] and out[2 * li + 1] is None and grad_sink(mod._convs[li].bias, True) is None:
+                out[2 * li + 1] = torch.zeros_like(mod._convs[li].bias)
+        ctx.gas = ctx.gzs = None
+        return (None,) * 9 + tuple(out)

@@ -395,6 +395,27 @@ def g_epilogue_bwd(gout, x, x_fake, cp: int, gx: Optional[torch.Tensor]):
 # --------------------------------------------------------------------------- #
 # elementwise / reductions
 # --------------------------------------------------------------------------- #
+def act_fwd(z: torch.Tensor, act: float) -> torch.Tensor:
+    a = torch.empty_like(z)
+    check(L.load().fcd_act_fwd(ptr(z), ptr(a), z.numel(), act, stream()), "act_fwd")
+    return a
+
+
+def act_bwd(g: torch.Tensor, z: torch.Tensor, act: float, out: Optional[torch.Tensor] = None, accumulate: bool = False):
+    """out (+)= g * act'(z)."""
+    if out is None:
+        out = torch.empty_like(z)
+    check(L.load().fcd_act_bwd(ptr(g), ptr(z), ptr(out), z.numel(), act, int(accumulate), stream()), "act_bwd")
+    return out
+
+
+def act_bwd2(ubar: torch.Tensor, ga: torch.Tensor, z: torch.Tensor, act: float):
+    """(ubar * act'(z), ubar * ga * act''(z))."""
+    u, q = torch.empty_like(z), torch.empty_like(z)
+    check(L.load().fcd_act_bwd2(ptr(ubar), ptr(ga), ptr(z), ptr(u), ptr(q), z.numel(), act, stream()), "act_bwd2")
+    return u, q
+
+
 def colsum(x2d_rows: int, x: torch.Tensor, c: int, out: Optional[torch.Tensor] = None, accumulate: bool = False):
     lib = L.load()
     if out is None:

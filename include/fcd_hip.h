@@ -210,6 +210,18 @@ int fcd_nhwc_to_nchw(const float* x, float* out, int accumulate, int N, int C, i
 /* g * (y > 0 ? 1 : slope): LeakyReLU backward from the (in-place) output sign,
  * fixed_point_gan.py:115. */
 int fcd_lrelu_bwd(const float* g, const float* y, float* out, size_t n, float slope, void* stream);
+/* Smooth discriminator activations (act = FCD_ACT_SILU / FCD_ACT_MISH; a slope in [0,1] also works),
+ * fixed_point_gan.py:13-16, 114-115, evaluated at the stored pre-activation z:
+ *   fcd_act_fwd:  a = act(z)
+ *   fcd_act_bwd:  out (+)= g * act'(z)                       (first backward)
+ *   fcd_act_bwd2: u_out = ubar * act'(z), q_out = ubar * ga * act''(z)
+ *                 (backward of the first backward, as the gradient penalty of
+ *                  fcd_solver.py:227-239 needs it: ubar is the cotangent of g * act'(z), ga the g of
+ *                  the first backward; q_out is the cotangent that flows on into z). */
+int fcd_act_fwd(const float* z, float* a, size_t n, float act, void* stream);
+int fcd_act_bwd(const float* g, const float* z, float* out, size_t n, float act, int accumulate, void* stream);
+int fcd_act_bwd2(const float* ubar, const float* ga, const float* z, float* u_out, float* q_out, size_t n,
+                 float act, void* stream);
 /* out[c] (+)= sum over rows of x[rows][C]: bias gradients. */
 int fcd_colsum(const float* x, float* out, int accumulate, size_t rows, int C, void* workspace,
                size_t workspace_bytes, void* stream);

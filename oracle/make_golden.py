@@ -345,6 +345,8 @@ VARIANTS = {
     "relu_d": ("lrelu", "relu", 2, False, False),
     "silu_g": ("silu", "lrelu", 4, False, False),
     "mish_g": ("mish", "lrelu", 4, False, True),
+    "silu_d": ("relu", "silu", 2, False, True),
+    "mish_d": ("silu", "mish", 2, True, True),
 }
 
 

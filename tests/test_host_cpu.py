@@ -97,7 +97,7 @@ def test_product_path_fails_loudly_on_cpu():
     with pytest.raises(NotImplementedError):
         Generator(8, 1, 1, 10, activation="gelu")
     with pytest.raises(NotImplementedError):
-        Discriminator(16, 8, 1, 2, 10, activation="mish")
+        Discriminator(16, 8, 1, 2, 10, activation="gelu")
     with pytest.raises(NotImplementedError):
         Discriminator(16, 8, 1, 2, 10, use_attention=True)
     # interm_non_act keeps the reference's key layout (Sequential(act, conv): conv at index 1)

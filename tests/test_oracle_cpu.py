@@ -132,7 +132,8 @@ def test_oracle_variants_match_reference_fixtures():
     import pytest
     variants = {"feats": ("relu", "lrelu", 2, False, True), "non_act": ("relu", "lrelu", 2, True, True),
                 "non_act_allfeat": ("relu", "lrelu", 4, True, True), "relu_d": ("lrelu", "relu", 2, False, False),
-                "silu_g": ("silu", "lrelu", 4, False, False), "mish_g": ("mish", "lrelu", 4, False, True)}
+                "silu_g": ("silu", "lrelu", 4, False, False), "mish_g": ("mish", "lrelu", 4, False, True),
+                "silu_d": ("relu", "silu", 2, False, True), "mish_d": ("silu", "mish", 2, True, True)}
     z, sc, gs, _, _ = load_tiny()
     cfg = sc["cfg"]
     v = np.load(os.path.join(GOLD, "tiny_variants.npz"))

@@ -317,6 +317,8 @@ VARIANTS = {
     "relu_d": ("lrelu", "relu", 2, False, False),
     "silu_g": ("silu", "lrelu", 4, False, False),
     "mish_g": ("mish", "lrelu", 4, False, True),
+    "silu_d": ("relu", "silu", 2, False, True),
+    "mish_d": ("silu", "mish", 2, True, True),
 }
 
 
@@ -340,15 +342,21 @@ def build_variant(name, cfg, dev):
 
 
 @pytest.mark.parametrize("name", list(VARIANTS))
-@pytest.mark.parametrize("prec", ["fp32", "fp32x3"])
+@pytest.mark.parametrize("prec", ["fp32", "fp32x3", "fp32-arena"])
 def test_variant_steps(dev, tiny, name, prec):
+    """prec 'fp32-arena': gradients accumulated by the kernels straight into the flat arenas
+    (the training path) instead of being returned through autograd."""
     from oracle import fcd_oracle as O
     z, sc = tiny
     v = np.load(os.path.join(GOLD, "tiny_variants.npz"))
     cfg = sc["cfg"]
     batch, alpha = O.synth_batch(cfg["batch"], cfg["size"], cfg["bands"])
     b = tuple(t.to(dev) for t in batch)
+    arena = prec.endswith("-arena")
+    prec = prec.split("-")[0]
     s = build_variant(name, cfg, dev)
+    if arena:
+        s.optimizers()
     s.set_precision(prec)
     with torch.no_grad():
         src, _, feat = s.D(b[0])
@@ -368,6 +376,8 @@ def test_variant_steps(dev, tiny, name, prec):
         assert e <= TOL, (name, pname, e)
     # G step (fresh modules: running statistics as in the fixture)
     s = build_variant(name, cfg, dev)
+    if arena:
+        s.optimizers()
     s.set_precision(prec)
     s.D.requires_grad_(False)
     s.global_step = s.n_critic - 1
