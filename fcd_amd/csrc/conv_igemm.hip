@@ -227,11 +227,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
   constexpr int RPI = 8 * NW;                   // tile rows one DMA instruction of every wave covers
-  static_assert(!BPRE || (PREC == FCD_PREC_BF16X3 && BN % (2 * NW) == 0 && !N16), "BPRE shape");
-  // BPRE: a B row is 3 planes x 4 chunks (32 bf16 each); one DMA instruction covers 16 rows of a plane
-  constexpr int BROWCH = BPRE ? 12 : 8;         // float4 chunks per B row
-  constexpr int AL = BM / RPI, BL = BPRE ? 3 * BN / (16 * NW) : BN / RPI;   // DMA instructions per wave per K-tile
-  constexpr int STAGE = BM * 8 + BN * BROWCH;   // float4 chunks per stage
+  static_assert(!BPRE || (PREC == FCD_PREC_BF16X3 && BN % 16 == 0 && !N16), "BPRE shape");
+  // BPRE: a B row is 3 planes x 4 chunks (32 bf16 each); one DMA instruction ("unit") covers 16 rows of
+  // a plane; units past 3*BN/16 (BN = 64: 12 units on 8 waves) are all-out-of-range dummies
+  constexpr int BUNITS = 3 * BN / 16;
+  constexpr int AL = BM / RPI, BL = BPRE ? (BUNITS + NW - 1) / NW : BN / RPI;   // DMA instructions per wave per K-tile
+  constexpr int STAGE = BM * 8 + (BPRE ? BL * NW * 64 : BN * 8);   // float4 chunks per stage
   static_assert((NW == 4 || NW == 8) && S >= 2 && BM % RPI == 0 && BN % RPI == 0 && TM >= 1 && TN >= 1, "shape");
 
   __shared__ float4 smem[S * STAGE + BM / 2];   // ring + rowoff (BM longs)
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
     for (int i = 0; i < BL; ++i) {
       const int ii = wave + NW * i, plane = ii / (BN / 16), row = 16 * (ii % (BN / 16)) + (lane >> 2);
       const int co = tn * BN + row, chunk = (lane & 3) ^ ((row >> 2) & 3);
-      b_base[i] = co < p.Cout ? (unsigned)((((long)plane * p.Cout + co) * p.K + chunk * 8) * 2) : OOB;
+      b_base[i] = (co < p.Cout && ii < BUNITS) ? (unsigned)((((long)plane * p.Cout + co) * p.K + chunk * 8) * 2) : OOB;
     }
   } else {
 #pragma unroll
@@ -1268,12 +1269,12 @@ int gather_wave_rows(int bm, int bn) {
   return 32;
 }
 
-// FCD_PREC_BF16X3 with 128x128 tiles and 32-channel K slices: the kernel takes pre-split weights
+// FCD_PREC_BF16X3 with 128x128 / 128x64 tiles and 32-channel K slices: the kernel takes pre-split weights
 bool wants_split_weights(const FcdConvDesc* d) {
   if (d->precision != FCD_PREC_BF16X3 || d->Cin % 32 != 0) return false;
   int bm, bn;
   gather_tile(d, bm, bn);
-  return bm == 128 && bn == 128;
+  return bm == 128 && (bn == 128 || bn == 64);
 }
 
 int run_gather(const FcdConvDesc* d, GatherArgs& a, hipStream_t st) {
@@ -1281,11 +1282,16 @@ int run_gather(const FcdConvDesc* d, GatherArgs& a, hipStream_t st) {
   gather_tile(d, bm, bn);
   if (wants_split_weights(d)) {
     a.tiles_m = fcd_cdiv(a.M, 128);
-    a.tiles_n = fcd_cdiv(d->Cout, 128);
+    a.tiles_n = fcd_cdiv(d->Cout, bn);
     a.w_phase_stride = (long)d->Cout * a.K * 3 / 2;      // three bf16 planes, in units of 4 bytes
     dim3 grid(a.tiles_m * a.tiles_n, a.nphase * a.splitk);
-    hipLaunchKernelGGL((conv_gather_dma_kernel<128, 128, 4, 2, 3, FCD_PREC_BF16X3, false, true>), grid, dim3(512), 0, st, a,
-                       (unsigned)((size_t)a.N * a.IH * a.IW * a.Cin * 4), (unsigned)((size_t)a.Cout * a.K * 6));
+    const unsigned in_bytes = (unsigned)((size_t)a.N * a.IH * a.IW * a.Cin * 4), w_bytes = (unsigned)((size_t)a.Cout * a.K * 6);
+    if (bn == 128)
+      hipLaunchKernelGGL((conv_gather_dma_kernel<128, 128, 4, 2, 3, FCD_PREC_BF16X3, false, true>), grid, dim3(512), 0, st, a,
+                         in_bytes, w_bytes);
+    else
+      hipLaunchKernelGGL((conv_gather_dma_kernel<128, 64, 4, 2, 3, FCD_PREC_BF16X3, false, true>), grid, dim3(512), 0, st, a,
+                         in_bytes, w_bytes);
     rc = fcd_check_launch("conv_gather");
     if (rc) return rc;
     if (a.splitk > 1) {
