@@ -28,12 +28,19 @@ PEAK_TFLOPS = {"fp32": 157.3, "fp32x3": 157.3, "bf16": 2500.0}   # MI355X_MICROA
 
 
 def is_dominant(d):
-    """The hottest launch: 3x3 s1 256->256 conv at 32x32, B=16 (residual blocks, forward and dgrad)."""
-    return (d.Cin == 256 and d.Cout == 256 and d.KH == 3 and d.KW == 3 and d.IH == 32 and d.IW == 32
-            and d.N == BASE["batch"] and d.nphase == 1)
+    """Tag for ops.KernelTimer.  'dominant': the hottest launch, 3x3 s1 256->256 conv at 32x32, B=16
+    (residual blocks, forward and dgrad).  'symbol': every other launch that runs the same kernel
+    symbol (the 128x128-tile gather kernel: Cout > 64 and more than 64 output pixels per phase) --
+    rocprofv3's per-kernel average is over all of these."""
+    if (d.Cin == 256 and d.Cout == 256 and d.KH == 3 and d.KW == 3 and d.IH == 32 and d.IW == 32
+            and d.N == BASE["batch"] and d.nphase == 1):
+        return "dominant"
+    if d.Cout > 64 and d.N * d.GH * d.GW > 64:
+        return "symbol"
+    return None
 
 
-def dominant_kernel_roofline(precision, dev, in_step_us=None, in_step_launches=0, iters=20):
+def dominant_kernel_roofline(precision, dev, in_step_us=None, in_step_launches=0, iters=20, symbol=None):
     """The hottest kernel: 3x3 s1 256->256 conv at 32x32, B=16 (forward form; dgrad runs the
     same kernel with flipped taps).  FLOPs per launch = 2*B*Cin*Cout*9*H*W.  `achieved` uses the
     average duration of this launch inside the timed training steps (HIP events around each of its
@@ -75,6 +82,15 @@ def dominant_kernel_roofline(precision, dev, in_step_us=None, in_step_launches=0
         # profiles/r1_k_resblock_conv_x3_pmc_*.csv: FETCH_SIZE 22136 KB x 2 + WRITE_SIZE 16384 KB (the
         # weights travel as three bf16 planes: 3.5 MB instead of 2.4 MB per XCD)
         traffic = 2 * 22136 * 1024 + 16384 * 1024
+    if symbol is not None:
+        # all launches of the same kernel symbol in the instrumented steps (what rocprofv3 --stats averages)
+        cnt, us, fl = symbol
+        extra["kernel_symbol_all_shapes"] = {
+            "launches_per_step": cnt // 2, "avg_us_per_launch": round(us / max(1, cnt), 2),
+            "achieved": round(fl / (us * 1e-6) / 1e12, 2), "frac": round(fl / (us * 1e-6) / 1e12 / peak, 4),
+            "note": "every launch of conv_gather_dma_kernel<128,128,...> in 2 training steps (all layer shapes; "
+                    "launches with fused InstanceNorm statistics include their ~6 us finalize kernel): compare "
+                    "with the per-kernel average of profiles/*_kernel_stats.csv"}
     return {**extra, "bound": "mfma", "kernel": "conv_gather_dma_kernel<128,128> 3x3 256->256 @32x32 B16",
             "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
             "us_per_launch": round(ms * 1e3, 2), "launches_timed": in_step_launches,
@@ -276,8 +292,9 @@ def main():
                           "global_batch": BASE["batch"] * world, "parallelism": f"dp{world}",
                           "precision": args.precision},
                "step_tflops": round(GFLOP_PER_IMG * BASE["batch"] / (ms * 1e-3) / 1e3, 2)}
-        res["roofline"] = dominant_kernel_roofline(args.precision, dev, timer.mean_us() if timer.pairs else None,
-                                                   len(timer.pairs))
+        res["roofline"] = dominant_kernel_roofline(args.precision, dev,
+                                                   timer.mean_us("dominant") if timer.pairs else None,
+                                                   timer.count("dominant"), symbol=timer.total() if timer.pairs else None)
         if args.precision == "fp32x3" and world == 1:
             # the same step with exact-fp32 MFMA everywhere (v_mfma_f32_32x32x2_f32), for reference
             solver.set_precision("fp32")

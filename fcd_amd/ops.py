@@ -140,12 +140,26 @@ class KernelTimer:
     time the dominant kernel inside the real training steps)."""
 
     def __init__(self, match):
-        self.match = match
-        self.pairs = []
+        self.match = match      # ConvDesc -> tag (truthy) for launches to time, falsy otherwise
+        self.pairs = []         # (start event, end event)
+        self.info = []          # (tag, algorithmic FLOPs of the launch), aligned with pairs
 
-    def mean_us(self) -> float:
+    def note(self, tag, d: ConvDesc) -> None:
+        self.info.append((tag, 2.0 * d.N * d.GH * d.GW * d.nphase * d.Cout * d.KH * d.KW * d.Cin))
+
+    def mean_us(self, tag=None) -> float:
         torch.cuda.synchronize()
-        return sum(a.elapsed_time(b) for a, b in self.pairs) / max(1, len(self.pairs)) * 1e3
+        sel = [p for p, (t, _) in zip(self.pairs, self.info) if tag is None or t == tag]
+        return sum(a.elapsed_time(b) for a, b in sel) / max(1, len(sel)) * 1e3
+
+    def count(self, tag=None) -> int:
+        return sum(1 for t, _ in self.info if tag is None or t == tag)
+
+    def total(self):
+        """(launches, summed microseconds, summed algorithmic FLOPs) over everything timed."""
+        torch.cuda.synchronize()
+        us = sum(a.elapsed_time(b) for a, b in self.pairs) * 1e3
+        return len(self.pairs), us, sum(f for _, f in self.info)
 
 
 KERNEL_TIMER: Optional[KernelTimer] = None
@@ -180,6 +194,7 @@ def conv_gather(d: ConvDesc, x: torch.Tensor, w_packed: torch.Tensor, bias=None,
     if timed:
         e1.record()
         KERNEL_TIMER.pairs.append((e0, e1))
+        KERNEL_TIMER.note(timed, d)
     return out
 
 
@@ -205,6 +220,7 @@ def conv_gather_stats(d: ConvDesc, x: torch.Tensor, w_packed: torch.Tensor, want
     if timed:       # includes the (few microseconds) finalize kernel that follows the convolution
         e1.record()
         KERNEL_TIMER.pairs.append((e0, e1))
+        KERNEL_TIMER.note(timed, d)
     return out, mean, rstd, varu
 
 
