@@ -28,26 +28,27 @@ PEAK_TFLOPS = {"fp32": 157.3, "fp32x3": 157.3, "bf16": 2500.0}   # MI355X_MICROA
 
 
 def is_dominant(d):
-    """Tag for ops.KernelTimer.  'dominant': the hottest launch, 3x3 s1 256->256 conv at 32x32, B=16
-    (residual blocks, forward and dgrad).  'symbol': every other launch that runs the same kernel
+    """Tag for ops.KernelTimer.  'dominant': the hottest launch, 3x3 s1 256->256 conv at 32x32 on the
+    G step's paired batch of 2 x 16 samples (residual blocks, forward and dgrad).  'symbol': every other launch that runs the same kernel
     symbol (the 128x128-tile gather kernel: Cout > 64 and more than 64 output pixels per phase) --
     rocprofv3's per-kernel average is over all of these."""
     if (d.Cin == 256 and d.Cout == 256 and d.KH == 3 and d.KW == 3 and d.IH == 32 and d.IW == 32
-            and d.N == BASE["batch"] and d.nphase == 1):
-        return "dominant"
+            and d.N == 2 * BASE["batch"] and d.nphase == 1):
+        return "dominant"      # the G step runs the generator on paired batches (2 x 16 samples per call)
     if d.Cout > 64 and d.N * d.GH * d.GW > 64:
         return "symbol"
     return None
 
 
 def dominant_kernel_roofline(precision, dev, in_step_us=None, in_step_launches=0, iters=20, symbol=None):
-    """The hottest kernel: 3x3 s1 256->256 conv at 32x32, B=16 (forward form; dgrad runs the
-    same kernel with flipped taps).  FLOPs per launch = 2*B*Cin*Cout*9*H*W.  `achieved` uses the
+    """The hottest kernel: 3x3 s1 256->256 conv at 32x32 on 32 samples (the G step pairs the reference's
+    B=16 generator calls; forward form; dgrad runs the same kernel with flipped taps).  FLOPs per launch
+    = 2*32*Cin*Cout*9*H*W.  `achieved` uses the
     average duration of this launch inside the timed training steps (HIP events around each of its
     launches on the launch stream); the back-to-back loop below is reported beside it."""
     from fcd_amd import _lib as L, ops
     g = ops.ConvGeom(256, 256, 3, 1, 1)
-    n, h, w = BASE["batch"], 32, 32
+    n, h, w = 2 * BASE["batch"], 32, 32
     x = torch.randn(n, h, w, 256, device=dev)
     wt = torch.randn(256, 256, 3, 3, device=dev) / 48.0
     prec = {"fp32": L.PREC_F32, "fp32x3": L.PREC_BF16X3, "bf16": L.PREC_BF16}[precision]
@@ -68,10 +69,10 @@ def dominant_kernel_roofline(precision, dev, in_step_us=None, in_step_launches=0
     flops = 2.0 * n * 256 * 256 * 9 * h * w
     achieved = flops / (ms * 1e-3) / 1e12
     peak = PEAK_TFLOPS[precision]
-    # HBM-side bytes per launch of this same launch from the rocprofv3 PMC passes committed under
-    # profiles/r1_e_resblock_conv_pmc_*.csv: FETCH_SIZE 17507 KB x 2 (gfx950 correction) + WRITE_SIZE
-    # 16384 KB; algorithmic: 16.8 MB input + 2.4 MB weights + 16.8 MB output.  fp32 launch only.
-    traffic = 2 * 17507 * 1024 + 16384 * 1024 if precision in ("fp32", "fp32x3") else None
+    # HBM-side bytes per launch of this same launch (32 samples) from the rocprofv3 PMC passes committed
+    # under profiles/r1_p_resblock_conv_fp32_b32_pmc_*.csv: FETCH_SIZE 34936.5 KB x 2 (gfx950 correction)
+    # + WRITE_SIZE 32768 KB; algorithmic: 33.6 MB input + 2.4 MB weights + 33.6 MB output.
+    traffic = int(2 * 34936.5 * 1024) + 32768 * 1024 if precision in ("fp32", "fp32x3") else None
     extra = {}
     if precision == "fp32x3":
         # six bf16 MFMAs per fp32 product group: the scheme's own ceiling is the bf16 peak / 6
@@ -79,9 +80,9 @@ def dominant_kernel_roofline(precision, dev, in_step_us=None, in_step_launches=0
         extra = {"executed_bf16_tflops": round(6 * achieved, 1), "fp32_mfma_peak": PEAK_TFLOPS["fp32"],
                  "note": "algorithmic fp32 FLOPs; peak = dense bf16 MFMA peak / 6 (six bf16 MFMAs per fp32 product group); "
                          "the exact-fp32 MFMA pipe peaks at 157.3"}
-        # profiles/r1_k_resblock_conv_x3_pmc_*.csv: FETCH_SIZE 22136 KB x 2 + WRITE_SIZE 16384 KB (the
+        # profiles/r1_p_resblock_conv_x3_b32_pmc_*.csv: FETCH_SIZE 44168 KB x 2 + WRITE_SIZE 32768 KB (the
         # weights travel as three bf16 planes: 3.5 MB instead of 2.4 MB per XCD)
-        traffic = 2 * 22136 * 1024 + 16384 * 1024
+        traffic = 2 * 44168 * 1024 + 32768 * 1024
     if symbol is not None:
         # all launches of the same kernel symbol in the instrumented steps (what rocprofv3 --stats averages)
         cnt, us, fl = symbol
@@ -91,7 +92,7 @@ def dominant_kernel_roofline(precision, dev, in_step_us=None, in_step_launches=0
             "note": "every launch of conv_gather_dma_kernel<128,128,...> in 2 training steps (all layer shapes; "
                     "launches with fused InstanceNorm statistics include their ~6 us finalize kernel): compare "
                     "with the per-kernel average of profiles/*_kernel_stats.csv"}
-    return {**extra, "bound": "mfma", "kernel": "conv_gather_dma_kernel<128,128> 3x3 256->256 @32x32 B16",
+    return {**extra, "bound": "mfma", "kernel": "conv_gather_dma_kernel<128,128> 3x3 256->256 @32x32, 32 samples per launch (two paired B=16 calls)",
             "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
             "us_per_launch": round(ms * 1e3, 2), "launches_timed": in_step_launches,
             "timed": "HIP events around every launch of this kernel in 2 training steps run right after the timed "

@@ -15,6 +15,7 @@ convolutions, weight gradients as split-K GEMMs).  Activations inside are NHWC.
 from __future__ import annotations
 
 import math
+import contextlib
 from typing import List, Optional
 
 import torch
@@ -164,6 +165,21 @@ class Generator(nn.Module):
         plan.append(_Layer("conv", ConvGeom(num_channels, d, 7, 1, 3), cl, None, 1.0))
         self.main = nn.Sequential(*mods)
         self._plan = plan
+        self._groups = 1
+
+    @contextlib.contextmanager
+    def sample_groups(self, groups: int):
+        """Inside this context a forward call on a batch of ``groups * B`` samples stands for
+        ``groups`` consecutive reference calls on ``B`` samples each: InstanceNorm couples nothing
+        across samples, so the outputs and gradients are those of the separate calls, and the tracked
+        running statistics are updated once per group, in order, exactly as the separate calls would
+        (``fcd_solver.py:316-357`` makes four generator calls per G step; the solver batches them in
+        pairs so that every launch-bound kernel runs half as often)."""
+        prev, self._groups = self._groups, int(groups)
+        try:
+            yield
+        finally:
+            self._groups = prev
 
     # parameters in plan order: (conv.weight, norm.weight, norm.bias)*
     def _flat_params(self):
@@ -192,6 +208,8 @@ class _GeneratorFn(torch.autograd.Function):
         prec = mod.precision
         training = mod.training
         plan = mod._plan
+        if n % mod._groups:
+            raise RuntimeError(f"Generator: batch {n} is not a multiple of sample_groups({mod._groups})")
         cp = plan[0].geom.IP
         acts = [ops.g_prologue(x, c, cp)]      # acts[i] = input of layer i
         saved = []                              # per layer: (z, mean, rstd, use_running)
@@ -223,7 +241,10 @@ class _GeneratorFn(torch.autograd.Function):
             if use_running:
                 mean, rstd = ops.instnorm_stats_from_running(nm.running_mean, nm.running_var, n)
             elif nm.track:
-                ops.instnorm_update_running(nm.running_mean, nm.running_var, mean, varu)
+                gsz = n // mod._groups
+                for gi in range(mod._groups):      # one momentum update per reference call
+                    ops.instnorm_update_running(nm.running_mean, nm.running_var, mean[gi * gsz:(gi + 1) * gsz],
+                                                varu[gi * gsz:(gi + 1) * gsz])
             res = acts[li + 1 + ly.res_from] if ly.res_from is not None else None
             y = ops.instnorm_apply(z, mean, rstd, gamma.detach(), beta.detach(), ly.act_slope, residual=res)
             saved.append((z, mean, rstd, use_running))

@@ -166,6 +166,8 @@ class FCDSolver(nn.Module):
         self.alpha_override: Optional[torch.Tensor] = None   # inject alpha (fcd_solver.py:296) for parity tests
         self.grad_sync = None                       # parallel.GradSync when data-parallel
         self.overlap_comm = True                    # overlap D's gradient all-reduce with the G step's start
+        self.pair_g_calls = True                    # G step: the four generator calls as two paired-batch calls
+        self.pair_d_calls = True                    # D step: D(x_real) and D(x_fake) as one paired-batch call
         self._pending = None
         self._val_cm = None
         self.build_model()
@@ -236,6 +238,13 @@ class FCDSolver(nn.Module):
         raise NotImplementedError(dataset)
 
     @staticmethod
+    def _pair_fits(x, widest: int) -> bool:
+        """A paired batch doubles every activation: pair only while the largest one (full resolution,
+        `widest` channels, fp32) stays below the library's 2 GiB operand limit (32-bit buffer offsets)."""
+        n, _, h, w = x.shape
+        return 2 * n * h * w * max(int(widest), 12) * 4 < (1 << 31)
+
+    @staticmethod
     def _feat_l1(real_feats, other_feats):
         terms = [losses.l1_mean(a.detach(), b) for a, b in zip(real_feats, other_feats)]
         return terms[0] if len(terms) == 1 else torch.mean(torch.stack(terms))
@@ -251,13 +260,22 @@ class FCDSolver(nn.Module):
         loss = None
         if optimizer_idx == 0:
             # ---- train the discriminator (fcd_solver.py:279-308)
-            out_src, out_cls, _ = self.D(x_real)
-            d_loss_real = losses.mean_scaled(out_src, -1.0)
-            d_loss_cls = self.classification_loss(out_cls, label_org, self.dataset)
+            if self.pair_d_calls and self._pair_fits(x_real, self.d_conv_dim // 4):
+                # D(x_real) and D(x_fake) as one call on the paired batch (D has no cross-sample coupling)
+                nb = x_real.size(0)
+                x_fake = self.G(x_real, c_trg)
+                src2, cls2, _ = self.D(torch.cat([x_real, x_fake.detach()]))
+                d_loss_real = losses.mean_scaled(src2[:nb], -1.0)
+                d_loss_cls = self.classification_loss(cls2[:nb], label_org, self.dataset)
+                d_loss_fake = losses.mean_scaled(src2[nb:], 1.0)
+            else:
+                out_src, out_cls, _ = self.D(x_real)
+                d_loss_real = losses.mean_scaled(out_src, -1.0)
+                d_loss_cls = self.classification_loss(out_cls, label_org, self.dataset)
 
-            x_fake = self.G(x_real, c_trg)
-            out_src, out_cls, _ = self.D(x_fake.detach())
-            d_loss_fake = losses.mean_scaled(out_src, 1.0)
+                x_fake = self.G(x_real, c_trg)
+                out_src, out_cls, _ = self.D(x_fake.detach())
+                d_loss_fake = losses.mean_scaled(out_src, 1.0)
 
             alpha = self._alpha(x_real.size(0), x_real.device)
             x_hat = ops.lerp_rows(x_real.detach().contiguous(), x_fake.detach().contiguous(),
@@ -273,21 +291,38 @@ class FCDSolver(nn.Module):
         elif optimizer_idx == 1:
             # ---- train the generator (fcd_solver.py:310-425)
             if (self.global_step + 1) % self.n_critic == 0:
-                x_fake = self.G(x_real, c_trg)
-                out_src, out_cls, _ = self.D(x_fake)
+                if self.pair_g_calls and self._pair_fits(x_real, self.g_conv_dim):
+                    # The reference's four generator calls as two calls on paired batches -- (x_real, c_trg)
+                    # with (x_real, c_org), then (x_fake, c_org) with (x_fake_id, c_org) -- and D once on
+                    # the first pair: per-sample results are those of the separate calls (InstanceNorm and
+                    # every loss term are per sample; Generator.sample_groups keeps the running-statistics
+                    # updates in the reference's order), and every launch-bound kernel runs half as often.
+                    nb = x_real.size(0)
+                    with self.G.sample_groups(2):
+                        fake2 = self.G(torch.cat([x_real, x_real]), torch.cat([c_trg, c_org]))
+                    x_fake, x_fake_id = fake2[:nb], fake2[nb:]
+                    src2, cls2, feats2 = self.D(fake2)
+                    out_src, out_cls = src2[:nb], cls2[:nb]
+                    out_src_id, out_cls_id, x_fake_id_feats = src2[nb:], cls2[nb:], [f[nb:] for f in feats2]
+                    with self.G.sample_groups(2):
+                        rec2 = self.G(fake2, torch.cat([c_org, c_org]))
+                    x_reconst, x_reconst_id = rec2[:nb], rec2[nb:]
+                else:
+                    x_fake = self.G(x_real, c_trg)
+                    out_src, out_cls, _ = self.D(x_fake)
+                    x_fake_id = self.G(x_real, c_org)
+                    out_src_id, out_cls_id, x_fake_id_feats = self.D(x_fake_id)
+                    x_reconst = self.G(x_fake, c_org)
+                    x_reconst_id = self.G(x_fake_id, c_org)
                 g_loss_fake = losses.mean_scaled(out_src, -1.0)
                 g_loss_cls = self.classification_loss(out_cls, label_trg, self.dataset)
 
-                x_fake_id = self.G(x_real, c_org)
-                out_src_id, out_cls_id, x_fake_id_feats = self.D(x_fake_id)
                 g_loss_fake_id = losses.mean_scaled(out_src_id, -1.0)
                 g_loss_cls_id = self.classification_loss(out_cls_id, label_org, self.dataset)
                 g_loss_id = losses.l1_mean(x_real, x_fake_id)
 
-                x_reconst = self.G(x_fake, c_org)
                 g_loss_rec = losses.l1_mean(x_real, x_reconst)
 
-                x_reconst_id = self.G(x_fake_id, c_org)
                 _, _, x_reconst_id_feats = self.D(x_reconst_id)    # reference :358
                 g_loss_rec_id = losses.l1_mean(x_real, x_reconst_id)
 

@@ -462,3 +462,37 @@ def test_other_shapes_vs_oracle(dev, name, prec):
     for k, v in ns.items():
         assert relerr(s.G.state_dict()[k], v) <= TOL, k
     print(f"shape {name} [{prec}] worst grad rel-err vs oracle {worst:.2e}")
+
+
+def test_paired_calls_equal_separate_calls(dev, tiny):
+    """The solver runs the G step's four generator calls as two paired-batch calls and the D step's
+    D(x_real), D(x_fake) as one (pair_g_calls / pair_d_calls): losses, gradients and the tracked
+    running statistics must be those of the reference's separate calls."""
+    z, sc = tiny
+    b = batch_of(z, dev)
+    out = {}
+    for paired in (True, False):
+        s = build(z, sc["cfg"], dev)
+        s.pair_g_calls = s.pair_d_calls = paired
+        s.alpha_override = torch.from_numpy(z["alpha"])
+        s.G.requires_grad_(False)
+        s.training_step(b, 0, 0).backward()
+        dl = {k: float(v) for k, v in s.loss_dict.items()}
+        dg = {n: p.grad.clone() for n, p in s.D.named_parameters()}
+        s.G.requires_grad_(True)
+        s.D.requires_grad_(False)
+        s.global_step = s.n_critic - 1
+        s.training_step(b, 0, 1).backward()
+        gl = {k: float(v) for k, v in s.loss_dict.items()}
+        gg = {n: p.grad.clone() for n, p in s.G.named_parameters()}
+        stats = {k: v.clone() for k, v in s.G.state_dict().items() if "running_" in k}
+        out[paired] = (dl, dg, gl, gg, stats)
+    (dl1, dg1, gl1, gg1, st1), (dl0, dg0, gl0, gg0, st0) = out[True], out[False]
+    for k in gl0:
+        assert abs(gl1[k] - gl0[k]) <= 2e-6 * max(1.0, abs(gl0[k])), k
+    for k in dg0:
+        assert relerr(dg1[k], dg0[k]) <= 2e-5, k
+    for k in gg0:
+        assert relerr(gg1[k], gg0[k]) <= 2e-5, k
+    for k in st0:      # same updates in the same order: bit-identical
+        assert torch.equal(st1[k], st0[k]), k

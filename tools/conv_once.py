@@ -4,7 +4,7 @@ from fcd_amd import _lib as L, ops
 prec = int(sys.argv[1]); sk = int(sys.argv[2])
 dev = torch.device('cuda:0')
 g = ops.ConvGeom(256, 256, 3, 1, 1)
-n, h, w = 16, 32, 32
+n, h, w = (int(sys.argv[3]) if len(sys.argv) > 3 else 16), 32, 32
 x = torch.randn(n, h, w, 256, device=dev); wt = torch.randn(256, 256, 3, 3, device=dev) / 48
 d = g.fwd_desc(n, h, w, precision=prec); d.splitk = sk
 wf = ops.pack_weight_fwd_x3(wt, g) if ops.wants_split_weights(d) else ops.pack_weight_fwd(wt, g)
