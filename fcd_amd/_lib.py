@@ -14,7 +14,8 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfcd_hip.so")
+# FCD_HIP_LIB: another build of the same library (A/B timing of kernel variants in one GPU session)
+LIB_PATH = os.environ.get("FCD_HIP_LIB") or os.path.join(_HERE, "libfcd_hip.so")
 
 PREC_F32 = 0
 PREC_BF16 = 1

@@ -312,7 +312,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
   // line are a few K-tiles apart and hit in L2 instead of a whole channel sweep apart.
   const int T = p.KH * p.KW;
   int k, tap, ci;
-  if (p.tap_inner) {
+  if (BPRE || p.tap_inner) {
     tap = kt0 % T;
     ci = (kt0 / T) * 32 + kc * 4;
     k = tap * p.Cin + ci;
@@ -355,7 +355,20 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
     }
   };
   auto issue_advance = [&]() {
-    if (p.tap_inner) {
+    if constexpr (BPRE) {
+      // (BPRE implies 32-channel slices, so the taps-inner order always applies, T = 1 included.)
+      // Branch-free on purpose: one basic block with the MFMAs around it, so that the scheduler can
+      // spread this bookkeeping between them instead of running it as a VALU-only tail (-1.4 %).
+      k += p.Cin;
+      tw += 1;
+      const bool ww = tw == p.KW;
+      tw = ww ? 0 : tw;
+      th += ww ? 1 : 0;
+      const bool wh = th == p.KH;
+      th = wh ? 0 : th;
+      ci += wh ? 32 : 0;
+      k += wh ? 32 - T * p.Cin : 0;
+    } else if (p.tap_inner) {
       k += p.Cin;
       if (++tw == p.KW) { tw = 0; ++th; }
       if (th == p.KH) { th = 0; ci += 32; k += 32 - T * p.Cin; }

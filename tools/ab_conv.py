@@ -1,0 +1,32 @@
+"""A/B time of the residual-block convolution (3x3 256->256 @32x32, 32 samples, fp32x3) between builds
+of the library (FCD_HIP_LIB per child process, builds alternate)."""
+import os, subprocess, sys
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+libs = sys.argv[1:]
+code = r'''
+import os, sys, torch
+sys.path.insert(0, %r)
+from fcd_amd import ops
+dev = torch.device('cuda:0')
+torch.manual_seed(0)
+g = ops.ConvGeom(256, 256, 3, 1, 1)
+n, h, w = 32, 32, 32
+x = torch.randn(n, h, w, 256, device=dev); wt = torch.randn(256, 256, 3, 3, device=dev) / 48
+d = g.fwd_desc(n, h, w, precision=2)
+wf = ops.pack_weight_fwd_x3(wt, g)
+out = ops.conv_gather(d, x, wf)
+for _ in range(200): ops.conv_gather(d, x, wf, out=out)
+res = []
+for rep in range(5):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(100): ops.conv_gather(d, x, wf, out=out)
+    e1.record(); torch.cuda.synchronize()
+    res.append(round(e0.elapsed_time(e1) * 10, 1))
+print(res)
+''' % root
+for rnd in range(2):
+    for lib in libs:
+        env = dict(os.environ, FCD_HIP_LIB=os.path.join(root, "fcd_amd", lib))
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        print(rnd, lib, out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr[-300:], flush=True)
