@@ -101,3 +101,39 @@ def test_pool_rejects_bad_positions():
         pool.gather(torch.tensor([len(pool)]))
     with pytest.raises(RuntimeError):
         pool.gather(torch.tensor([0]), ret_mask=True)
+
+
+def test_loader_feeds_train_and_validation_steps():
+    """End to end: patch pool -> PatchLoader -> on_before_batch_transfer -> train_step, then the
+    validation loader (masks alongside) -> validation_step / validation_epoch_end."""
+    from fcd_amd import FCDSolver
+    from fcd_amd.data_loader import L8BiomePatchPool, PatchLoader, on_before_batch_transfer
+    rng = np.random.default_rng(1)
+    n, size = 12, 32
+    images = rng.integers(1, 65536, size=(n, size, size, 10), dtype=np.uint16)
+    images[::3, :6, :9, :] = 0
+    masks = rng.integers(0, 3, size=(n, size, size), dtype=np.uint8)
+    labels = (masks == 2).any(axis=(1, 2)).astype(np.uint8)          # prepare_landsat8_biome.py:170
+    pool = L8BiomePatchPool(images, labels, masks)
+    s = FCDSolver(None, image_size=size, g_conv_dim=8, d_conv_dim=8, g_repeat_num=2, d_repeat_num=3, batch_size=4,
+                  precision="fp32x3").to("cuda")
+    w0 = s.G.main[0].weight.detach().clone()
+    g = torch.Generator().manual_seed(0)
+    steps = 0
+    for batch in PatchLoader(pool, batch_size=4, mode="train", generator=g, max_shift=2):
+        tup = on_before_batch_transfer(batch, generator=g)
+        assert tup[0].shape == (4, 10, size, size) and tup[1].shape == (4, 1)
+        d_loss, g_loss = s.train_step(tup, force_g=True)
+        assert torch.isfinite(d_loss) and torch.isfinite(g_loss)
+        steps += 1
+    assert steps == 3 and float((s.G.main[0].weight - w0).abs().max()) > 0
+    s.G.eval()
+    seen = 0
+    for batch in PatchLoader(pool, batch_size=4, mode="val", ret_mask=True):
+        tup = on_before_batch_transfer(batch)
+        assert len(tup) == 6 and tup[5].dtype == torch.uint8
+        s.validation_step(tup)
+        seen += tup[0].shape[0]
+    res = s.validation_epoch_end()
+    assert seen == n and int(res["confusion_matrix"].sum()) == int((masks > 0).sum())
+    assert 0.0 <= res["F1"] <= 1.0
