@@ -1070,6 +1070,96 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_dma_kernel(const Wgra
     }
 }
 
+// Weight gradient of a 7x7, stride-1, pad-3 convolution with at most 16 output channels (the
+// generator's last layer: dW[10][64][7][7]) -- the "halo" form.  The generic 16-row kernel above
+// streams the input once per tap (49 times through L2 -> LDS) and needs one DMA instruction per
+// four 16x16x4 MFMAs, which is what bounds it.  Here a workgroup owns (image, 16-channel group,
+// 64-column strip, row range) and keeps the 7 input rows a gradient row needs in an 8-slot ring
+// of LDS rows (70 pixels wide: 64 + 6 halo): every input row is loaded once, each of the 7 waves
+// owns one tap row th and accumulates its 7 taps tw from shifted reads of the same LDS rows.
+//   dW[o][i][th][tw] = sum_{y,x} g[y][x][o] * X[y+th-3][x+tw-3][i]
+// MFMA roles: M = o (16), N = i (16), K = pixels (4 per MFMA): lane (c = lane&15, q = lane>>4) feeds
+// A = g[x+q][c] and B = X[x+q+tw][c].  One barrier per gradient row; the next row's DMA (9
+// instructions per workgroup and row against 784 MFMAs) is issued before the row's MFMAs.
+constexpr int H7_CW = 64;     // gradient columns per workgroup
+constexpr int H7_XW = 80;     // pixels per LDS ring row: 70 used, padded to 5 whole DMA instructions
+constexpr int H7_WAVES = 7;
+__global__ __launch_bounds__(64 * H7_WAVES) void wgrad7_halo_kernel(const WgradArgs p, const int rows, const int R,
+                                                                   const int nch, const unsigned gs_bytes,
+                                                                   const unsigned xb_bytes) {
+  __shared__ float4 Xs[8 * H7_XW * 4];     // [ring slot][pixel][4 chunks = 16 channels]
+  __shared__ float4 Gs[2 * H7_CW * 4];     // [buffer][pixel][4 chunks = 16 output channels]
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int ch = blockIdx.x % nch, r = blockIdx.x / nch;
+  const int ncg = p.IP / 16;
+  const int cg = blockIdx.y % ncg, n = blockIdx.y / ncg;
+  const int x0 = ch * H7_CW, y0 = r * rows, y1 = min(p.GH, y0 + rows);
+  const i32x4 rgs = make_rsrc(p.gs, gs_bytes);
+  const i32x4 rxb = make_rsrc(p.xb, xb_bytes);
+  const unsigned lx = lds_addr_of(Xs), lg0 = lds_addr_of(Gs);
+  const int lpx = lane >> 2, lc = lane & 3;      // pixel within a DMA instruction, 16-byte chunk
+
+  // instruction j (0..4) of input row yy -> ring slot; j (0..3) of gradient row y -> buffer
+  auto issue_x = [&](int j, int yy) {
+    const int px = j * 16 + lpx, gx = x0 - 3 + px;
+    const bool ok = px < H7_CW + 6 && yy >= 0 && yy < p.BH && gx >= 0 && gx < p.BW;
+    const unsigned voff = ok ? (unsigned)((((n * p.BH + yy) * p.BW + gx) * p.IP + cg * 16 + lc * 4) * 4) : OOB;
+    dma16(rxb, voff, lx + (unsigned)((((yy + 16) & 7) * H7_XW * 4 + j * 64) * 16));
+  };
+  auto issue_g = [&](int j, int y) {
+    const int px = j * 16 + lpx, gx = x0 + px;
+    const bool ok = y < y1 && gx < p.GW && lc * 4 < p.OP;
+    const unsigned voff = ok ? (unsigned)((((n * p.GH + y) * p.GW + gx) * p.OP + lc * 4) * 4) : OOB;
+    dma16(rgs, voff, lg0 + (unsigned)(((y & 1) * H7_CW * 4 + j * 64) * 16));
+  };
+  // the 9 instructions of one row step, dealt round-robin to the 7 waves
+  auto issue_row = [&](int y) {
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      if (q % H7_WAVES != wave) continue;
+      if (q < 5) issue_x(q, y + 3);
+      else issue_g(q - 5, y);
+    }
+  };
+  for (int q = wave; q < 6 * 5; q += H7_WAVES) issue_x(q % 5, y0 - 3 + q / 5);   // rows y0-3 .. y0+2
+  issue_row(y0);                                                                  // row y0+3 and g row y0
+  wait_vmcnt<0>();
+  __syncthreads();
+
+  f32x4 acc[7];
+#pragma unroll
+  for (int t = 0; t < 7; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int c16 = lane & 15, q4 = lane >> 4;
+  const float* Xf = reinterpret_cast<const float*>(Xs);
+  const float* Gf = reinterpret_cast<const float*>(Gs);
+  const int th = wave;
+  for (int y = y0; y < y1; ++y) {
+    issue_row(y + 1);                       // past y1 / the image: out-of-range lanes write zeros
+    const float* Xrow = Xf + ((y + th - 3 + 16) & 7) * (H7_XW * 16) + q4 * 16 + c16;
+    const float* Grow = Gf + (y & 1) * (H7_CW * 16) + q4 * 16 + c16;
+#pragma unroll 4
+    for (int kk = 0; kk < H7_CW / 4; ++kk) {
+      const float a = Grow[kk * 64];
+#pragma unroll
+      for (int t = 0; t < 7; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Xrow[kk * 64 + t * 16], acc[t], 0, 0, 0);
+    }
+    wait_vmcnt<0>();
+    __syncthreads();
+  }
+  // D[o = 4*(lane>>4) + e][i = lane&15] of tap (th, t)
+  float* __restrict__ dst = p.slab + (long)((n * R + r) * nch + ch) * p.O * p.ND;
+#pragma unroll
+  for (int t = 0; t < 7; ++t) {
+    const int col = (th * 7 + t) * p.IP + cg * 16 + c16;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int o = 4 * q4 + e;
+      if (o < p.O) dst[(long)o * p.ND + col] = acc[t][e];
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void pack_fwd_kernel(const float* __restrict__ w, float* __restrict__ out,
                                                        int O, int I, int IP, int taps) {
   const long total = (long)O * taps * IP;
@@ -1417,6 +1507,27 @@ extern "C" int fcd_conv_gather_stats(const FcdConvDesc* d, const float* in, cons
   return fcd_finalize_stats((const double*)stats_ws, mean, rstd, var_unbiased, d->N, hw, d->CoutP, chunks, eps, st);
 }
 
+// The halo form of the 7x7, <= 16-output-channel weight gradient: number of split slabs it writes
+// (0 = not applicable), rows per workgroup, row ranges and column strips.
+static int halo7_plan(const FcdWgradDesc* d, int* rows, int* R, int* nch) {
+  if (d->splitk > 0 || d->precision == FCD_PREC_BF16) return 0;         // explicit split / bf16: generic kernels
+  if (d->KH != 7 || d->KW != 7 || d->stride != 1 || d->pad != 3 || d->O > 16 || d->OP > 16) return 0;
+  if (d->IP % 16 != 0 || d->BH != d->GH || d->BW != d->GW) return 0;
+  const int c = fcd_cdiv(d->GW, H7_CW);
+  const long base = (long)d->N * (d->IP / 16) * c;
+  // about one workgroup per CU: more, shorter row ranges only add halo loads and slab traffic
+  // (measured at N = 32: 521 us with 256 workgroups, 574 with 512, 723 with 1024)
+  long rr = (320 + base / 2) / base;
+  if (rr > d->GH / 8) rr = d->GH / 8;
+  if (rr < 1) rr = 1;
+  const int rw = fcd_cdiv(d->GH, (int)rr);
+  *rows = rw;
+  *R = fcd_cdiv(d->GH, rw);
+  *nch = c;
+  const long splits = (long)d->N * *R * c;
+  return splits <= 4096 ? (int)splits : 0;
+}
+
 static int wgrad_bm(const FcdWgradDesc* d) { return d->O <= 32 ? 32 : (d->O <= 64 ? 64 : (d->O <= 128 ? 128 : 256)); }
 
 static int resolve_wgrad_splitk(const FcdWgradDesc* d) {
@@ -1450,7 +1561,9 @@ static int validate_wgrad(const FcdWgradDesc* d) {
 
 extern "C" size_t fcd_wgrad_workspace_bytes(const FcdWgradDesc* d) {
   if (!d || d->O <= 0 || d->IP <= 0 || d->KH <= 0 || d->KW <= 0) return 0;
-  return (size_t)resolve_wgrad_splitk(d) * d->O * d->KH * d->KW * d->IP * sizeof(float);
+  int rows, R, nch;
+  const int halo = halo7_plan(d, &rows, &R, &nch);
+  return (size_t)(halo ? halo : resolve_wgrad_splitk(d)) * d->O * d->KH * d->KW * d->IP * sizeof(float);
 }
 
 extern "C" int fcd_conv_wgrad(const FcdWgradDesc* d, const float* gsmall, const float* xbig, float* dw,
@@ -1475,7 +1588,15 @@ extern "C" int fcd_conv_wgrad(const FcdWgradDesc* d, const float* gsmall, const 
   a.splitk = fcd_cdiv(a.ktiles, a.ktiles_per_split);
   a.accumulate = d->accumulate;
   hipStream_t st = fcd_stream(stream);
-  if (d->O <= 16 && d->precision != FCD_PREC_BF16) {   // exact fp32 16-row kernel, also under BF16X3
+  int h_rows = 0, h_R = 0, h_nch = 0;
+  const int halo = halo7_plan(d, &h_rows, &h_R, &h_nch);
+  if (halo) {                                           // exact fp32, input rows loaded once for all 49 taps
+    a.splitk = halo;
+    dim3 grid(h_nch * h_R, d->N * (d->IP / 16));
+    hipLaunchKernelGGL(wgrad7_halo_kernel, grid, dim3(64 * H7_WAVES), 0, st, a, h_rows, h_R, h_nch,
+                       (unsigned)((size_t)a.P * a.OP * 4), (unsigned)((size_t)a.N * a.BH * a.BW * a.IP * 4));
+    rc = fcd_check_launch("conv_wgrad");
+  } else if (d->O <= 16 && d->precision != FCD_PREC_BF16) {   // exact fp32 16-row kernel, also under BF16X3
     a.tiles_m = 1; a.tiles_n = fcd_cdiv(a.ND, 128);
     dim3 grid(a.tiles_n, a.splitk);
     hipLaunchKernelGGL((conv_wgrad_dma_kernel<32, 128, 1, 4, 3, FCD_PREC_F32, true>), grid, dim3(256), 0, st, a,

@@ -155,3 +155,41 @@ def test_conv_with_fused_instnorm_statistics(dev, geom, prec):
     zc = z1.cpu().double()
     assert relerr(m1, zc.mean((1, 2))) <= 1e-5
     assert relerr(v1, zc.var((1, 2), unbiased=True)) <= 1e-5
+
+
+# 7x7 / <= 16 output channels / input channels a multiple of 16: the halo weight-gradient kernel
+# (input rows loaded once for all 49 taps).  Ragged widths (column strips with out-of-range halo),
+# heights that do not divide into the row ranges, 3 / 10 / 16 output channels, accumulation.
+HALO_GEOMS = [
+    (10, 64, 2, 128, 128),
+    (10, 32, 3, 40, 100),
+    (16, 16, 1, 70, 64),
+    (3, 48, 2, 33, 130),
+    (12, 16, 5, 9, 7),
+]
+
+
+@pytest.mark.parametrize("prec", [0, 2])
+@pytest.mark.parametrize("geom", HALO_GEOMS)
+def test_wgrad_7x7_halo(dev, geom, prec):
+    from fcd_amd import ops
+    O, I, N, H, W = geom
+    g = ops.ConvGeom(O, I, 7, 1, 3)
+    torch.manual_seed(5)
+    x = torch.randn(N, I, H, W)
+    gy = torch.randn(N, O, H, W)
+    w = torch.zeros(O, I, 7, 7, dtype=torch.float64, requires_grad=True)
+    (F.conv2d(x.double(), w, None, 1, 3) * gy.double()).sum().backward()
+    ref = w.grad
+    d = g.wgrad_desc(N, H, W, precision=prec)
+    gyd, xd = to_nhwc(gy, g.OP).to(dev), to_nhwc(x, g.IP).to(dev)
+    dw = ops.conv_wgrad(d, gyd, xd)
+    assert relerr(dw.cpu(), ref) <= 1e-5
+    d.accumulate = 1
+    dw2 = ops.conv_wgrad(d, gyd, xd, dw.clone())
+    assert relerr(dw2.cpu(), 2 * ref) <= 1e-5
+    # the generic 16-row kernel (explicit split) computes the same thing
+    d2 = g.wgrad_desc(N, H, W, precision=prec)
+    d2.splitk = 3
+    dw3 = ops.conv_wgrad(d2, gyd, xd)
+    assert relerr(dw3.cpu(), dw.cpu()) <= 1e-5
