@@ -138,3 +138,26 @@ def test_full_train_steps_run_and_move_weights(full):
     # Adam's first steps move every weight by about lr
     assert 1e-5 < float((s.G.main[0].weight - w0).abs().max()) < 1e-3
     assert 1e-5 < float((s.D.conv1.weight - d0).abs().max()) < 1e-3
+
+
+def test_training_is_bitwise_reproducible(full):
+    """Ten full-size training steps, twice, from the same state: identical bits in every weight and
+    running statistic.  All reductions run in a fixed order and nothing in the training path uses
+    floating-point atomics, so any difference would mean a race (LDS-DMA waits, stream ordering of
+    the arena updates) -- tools/soak_probe.py is the 400-step version of this."""
+    import hashlib
+    sc, make, b, alpha = full
+
+    def run():
+        s = make("fp32x3")
+        s.alpha_override = alpha
+        for _ in range(10):
+            d_loss, g_loss = s.train_step(b, force_g=True)
+        assert torch.isfinite(d_loss) and torch.isfinite(g_loss)
+        h = hashlib.sha256()
+        for net in (s.G, s.D):
+            for v in net.state_dict().values():
+                h.update(v.detach().cpu().numpy().tobytes())
+        return h.hexdigest()
+
+    assert run() == run()
