@@ -41,6 +41,15 @@ def test_workspace_queries_run_without_gpu():
     w = ops.ConvGeom(256, 256, 3, 1, 1).wgrad_desc(16, 32, 32)
     assert lib.fcd_wgrad_workspace_bytes(ctypes.byref(w)) >= 256 * 9 * 256 * 4
     assert lib.fcd_instnorm_workspace_bytes(16, 1024, 256) > 0
+    # the 7x7 / 10-output-channel weight gradient takes the halo kernel: one slab per (image, row
+    # range, 64-column strip) = 32 * 1 * 2 splits of [10][49 * 64] floats; an explicit split-K or a
+    # channel count that is not a multiple of 16 falls back to the generic kernel's plan
+    h = ops.ConvGeom(10, 64, 7, 1, 3).wgrad_desc(32, 128, 128)
+    assert lib.fcd_wgrad_workspace_bytes(ctypes.byref(h)) == 64 * 10 * 49 * 64 * 4
+    h.splitk = 5
+    assert lib.fcd_wgrad_workspace_bytes(ctypes.byref(h)) == 5 * 10 * 49 * 64 * 4
+    h8 = ops.ConvGeom(10, 8, 7, 1, 3).wgrad_desc(2, 32, 32)
+    assert lib.fcd_wgrad_workspace_bytes(ctypes.byref(h8)) % (10 * 49 * 8 * 4) == 0
     # bad descriptors are rejected with a message, not a crash
     bad = g.fwd_desc(16, 8, 8)
     bad.Cin = 510
