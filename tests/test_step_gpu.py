@@ -496,3 +496,55 @@ def test_paired_calls_equal_separate_calls(dev, tiny):
         assert relerr(gg1[k], gg0[k]) <= 2e-5, k
     for k in st0:      # same updates in the same order: bit-identical
         assert torch.equal(st1[k], st0[k]), k
+
+
+def test_all_nodata_sample_and_constant_channels(dev):
+    """Domain edge cases: one sample of the batch is entirely nodata (every band -1: constant input,
+    zero variance in the first InstanceNorm's statistics path, output forced to -1 everywhere) and
+    another has a constant band.  Forward, losses and gradients against the float64 oracle."""
+    from fcd_amd import FCDSolver
+    from oracle import fcd_oracle as O
+    b, size, bands, c_dim, gcd, dcd, grep, drep = 3, 32, 10, 1, 8, 8, 2, 3
+    gs = O.synth_generator_state(gcd, c_dim, grep, bands)
+    ds = O.synth_discriminator_state(size, dcd, c_dim, drep, bands)
+    (x, c_org, c_trg, l_org, l_trg), alpha = O.synth_batch(b, size, bands, seed=21)
+    x = x.clone()
+    x[1] = -1.0                     # a patch without any valid pixel
+    x[2, 4] = 0.25                  # a constant band
+    batch = (x, c_org, c_trg, l_org, l_trg)
+    gs64, ds64 = O.to_dtype(gs, torch.float64), O.to_dtype(ds, torch.float64)
+    b64 = tuple(t.double() for t in batch)
+    with torch.no_grad():
+        ref_out = O.generator_forward(gs64, b64[0], b64[2], True, "relu", {})
+    _, dl, dg = O.d_step(gs64, ds64, b64, alpha.double(), new_stats={})
+    _, gl, gg = O.g_step(gs64, ds64, b64, new_stats={})
+
+    def make():
+        s = FCDSolver(None, c_dim=c_dim, image_size=size, g_conv_dim=gcd, d_conv_dim=dcd, g_repeat_num=grep,
+                      d_repeat_num=drep, num_channels=bands, batch_size=b)
+        s.G.load_state_dict(gs)
+        s.D.load_state_dict(ds)
+        return s.to(dev)
+
+    gb = tuple(t.to(dev) for t in batch)
+    s = make()
+    with torch.no_grad():
+        out = s.G(gb[0], gb[2])
+    assert bool((out[1] == -1).all()) and torch.isfinite(out).all()
+    assert relerr(out, ref_out) <= TOL
+    s = make()
+    s.alpha_override = alpha
+    s.G.requires_grad_(False)
+    s.training_step(gb, 0, 0).backward()
+    for k, v in dl.items():
+        assert abs(float(s.loss_dict[k]) - float(v)) <= TOL * max(1.0, abs(float(v))), k
+    for pname, p in s.D.named_parameters():
+        assert relerr(p.grad, dg[pname]) <= TOL, pname
+    s = make()
+    s.D.requires_grad_(False)
+    s.global_step = s.n_critic - 1
+    s.training_step(gb, 0, 1).backward()
+    for k, v in gl.items():
+        assert abs(float(s.loss_dict[k]) - float(v)) <= TOL * max(1.0, abs(float(v))), k
+    for pname, p in s.G.named_parameters():
+        assert torch.isfinite(p.grad).all() and relerr(p.grad, gg[pname]) <= TOL, pname
