@@ -122,7 +122,9 @@ def hbm_kernel_roofline(dev, iters=20):
     nbytes = 2.0 * z.numel() * 4
     return {"bound": "hbm", "kernel": "in_apply_kernel (16,128,128,64) fp32", "achieved": round(nbytes / (ms * 1e-3) / 1e9, 1),
             "peak": 8000.0, "unit": "GB/s", "frac": round(nbytes / (ms * 1e-3) / 8e12, 4),
-            "us_per_launch": round(ms * 1e3, 2), "mbytes_per_launch": round(nbytes / 1e6, 1)}
+            "us_per_launch": round(ms * 1e3, 2), "mbytes_per_launch": round(nbytes / 1e6, 1),
+            # profiles/r1_q_in_apply_pmc_*.csv: FETCH_SIZE 32854 KB x 2 (gfx950 correction) + WRITE_SIZE 65536 KB
+            "traffic": 2 * 32854 * 1024 + 65536 * 1024}
 
 
 def inference_rate(solver, dev, iters=5):
