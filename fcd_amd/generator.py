@@ -79,6 +79,28 @@ class ConvParams(nn.Module):
         return t
 
 
+    def folded(self, geom: ConvGeom, d, norm) -> tuple:
+        """Inference only: the forward operand with a tracked InstanceNorm's eval-mode transform folded
+        in.  With running statistics the norm is the per-channel affine map ``z * s + t``,
+        ``s = gamma / sqrt(running_var + eps)``, ``t = beta - running_mean * s`` (fcd_oracle
+        ``_instance_norm``, eval branch), so ``norm(conv(a, W)) == conv(a, W * s) + t``: the scaled weights
+        are packed once per set of parameter / buffer versions, ``t`` goes in as the bias, the activation
+        and the residual add ride in the convolution's epilogue, and no norm kernel runs at all."""
+        srcs = (self.weight, norm.weight, norm.bias, norm.running_mean, norm.running_var)
+        x3 = ops.wants_split_weights(d)
+        key = tuple((t.data_ptr(), t._version) for t in srcs) + (x3, str(self.weight.device))
+        hit = self._packed.get("folded")
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        with torch.no_grad():
+            scale = norm.weight.detach() / torch.sqrt(norm.running_var + ops.IN_EPS)
+            shift = (norm.bias.detach() - norm.running_mean * scale).contiguous()
+            wd = (self.weight.detach() * scale.view(-1, 1, 1, 1)).contiguous()
+            wp = (ops.pack_weight_fwd_x3 if x3 else ops.pack_weight_fwd)(wd, geom)
+        self._packed["folded"] = (key, (wp, shift))
+        return wp, shift
+
+
 class NormParams(nn.Module):
     """InstanceNorm2d(affine=True[, track_running_stats=True]) parameters and buffers."""
 
@@ -210,6 +232,7 @@ class _GeneratorFn(torch.autograd.Function):
         plan = mod._plan
         if n % mod._groups:
             raise RuntimeError(f"Generator: batch {n} is not a multiple of sample_groups({mod._groups})")
+        inference = not any(ctx.needs_input_grad)       # no backward will ask for the per-layer tensors
         cp = plan[0].geom.IP
         acts = [ops.g_prologue(x, c, cp)]      # acts[i] = input of layer i
         saved = []                              # per layer: (z, mean, rstd, use_running)
@@ -222,6 +245,15 @@ class _GeneratorFn(torch.autograd.Function):
             nm = ly.norm
             use_running = nm is not None and nm.track and not training
             fuse = nm is not None and not use_running      # statistics ride in the conv's epilogue
+            if use_running and inference and ly.kind == "conv" and ly.act_slope <= 1.0:
+                # eval-mode norm folded into the convolution (nothing is kept for a backward pass)
+                d = g.fwd_desc(n, a.shape[1], a.shape[2], precision=prec, act_slope=ly.act_slope)
+                wp, shift = ly.conv.folded(g, d, nm)
+                res = acts[li + 1 + ly.res_from] if ly.res_from is not None else None
+                acts.append(ops.conv_gather(d, a, wp, bias=shift, residual=res))
+                saved.append(None)
+                pi += 2                          # gamma, beta: folded into wp / shift
+                continue
             if ly.kind == "conv":
                 d = g.fwd_desc(n, a.shape[1], a.shape[2], precision=prec)
                 wp = ly.conv.operand("fwd", g, d)
