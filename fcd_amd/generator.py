@@ -82,8 +82,8 @@ class ConvParams(nn.Module):
     def folded(self, geom: ConvGeom, d, norm) -> tuple:
         """Inference only: the forward operand with a tracked InstanceNorm's eval-mode transform folded
         in.  With running statistics the norm is the per-channel affine map ``z * s + t``,
-        ``s = gamma / sqrt(running_var + eps)``, ``t = beta - running_mean * s`` (fcd_oracle
-        ``_instance_norm``, eval branch), so ``norm(conv(a, W)) == conv(a, W * s) + t``: the scaled weights
+        ``s = gamma / sqrt(running_var + eps)``, ``t = beta - running_mean * s`` (what
+        ``nn.InstanceNorm2d(track_running_stats=True)`` computes in eval mode, fixed_point_gan.py:28,31), so ``norm(conv(a, W)) == conv(a, W * s) + t``: the scaled weights
         are packed once per set of parameter / buffer versions, ``t`` goes in as the bias, the activation
         and the residual add ride in the convolution's epilogue, and no norm kernel runs at all."""
         srcs = (self.weight, norm.weight, norm.bias, norm.running_mean, norm.running_var)
