@@ -293,16 +293,22 @@ __global__ __launch_bounds__(256) void stats_from_running_kernel(const float* __
 
 __global__ __launch_bounds__(256) void update_running_kernel(float* __restrict__ rm, float* __restrict__ rv,
                                                              const float* __restrict__ mean, const float* __restrict__ varu,
-                                                             int N, int C, float momentum) {
+                                                             int N, int C, int groups, float momentum) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
-  float sm = 0.f, sv = 0.f;
-  for (int n = 0; n < N; ++n) {
-    sm += mean[(long)n * C + c];
-    sv += varu[(long)n * C + c];
+  const int gn = N / groups;
+  float m = rm[c], v = rv[c];
+  for (int g = 0; g < groups; ++g) {       // one update per reference call, in call order
+    float sm = 0.f, sv = 0.f;
+    for (int n = g * gn; n < (g + 1) * gn; ++n) {
+      sm += mean[(long)n * C + c];
+      sv += varu[(long)n * C + c];
+    }
+    m = (1.f - momentum) * m + momentum * (sm / (float)gn);
+    v = (1.f - momentum) * v + momentum * (sv / (float)gn);
   }
-  rm[c] = (1.f - momentum) * rm[c] + momentum * (sm / (float)N);
-  rv[c] = (1.f - momentum) * rv[c] + momentum * (sv / (float)N);
+  rm[c] = m;
+  rv[c] = v;
 }
 
 int check_nhwc(const char* what, int N, long HW, int C) {
@@ -359,10 +365,12 @@ extern "C" int fcd_instnorm_stats_from_running(const float* running_mean, const 
 }
 
 extern "C" int fcd_instnorm_update_running(float* running_mean, float* running_var, const float* mean,
-                                           const float* var_unbiased, int N, int C, float momentum, void* stream) {
+                                           const float* var_unbiased, int N, int C, int groups, float momentum,
+                                           void* stream) {
   FCD_REQUIRE(running_mean && running_var && mean && var_unbiased && N > 0 && C > 0, "update_running: bad arguments");
+  FCD_REQUIRE(groups >= 1 && N % groups == 0, "update_running: N=%d is not a multiple of groups=%d", N, groups);
   hipLaunchKernelGGL(update_running_kernel, dim3(fcd_cdiv(C, 256)), dim3(256), 0, fcd_stream(stream), running_mean,
-                     running_var, mean, var_unbiased, N, C, momentum);
+                     running_var, mean, var_unbiased, N, C, groups, momentum);
   return fcd_check_launch("update_running");
 }
 

@@ -273,10 +273,8 @@ class _GeneratorFn(torch.autograd.Function):
             if use_running:
                 mean, rstd = ops.instnorm_stats_from_running(nm.running_mean, nm.running_var, n)
             elif nm.track:
-                gsz = n // mod._groups
-                for gi in range(mod._groups):      # one momentum update per reference call
-                    ops.instnorm_update_running(nm.running_mean, nm.running_var, mean[gi * gsz:(gi + 1) * gsz],
-                                                varu[gi * gsz:(gi + 1) * gsz])
+                # one momentum update per reference call (sample group), in call order
+                ops.instnorm_update_running(nm.running_mean, nm.running_var, mean, varu, groups=mod._groups)
             res = acts[li + 1 + ly.res_from] if ly.res_from is not None else None
             y = ops.instnorm_apply(z, mean, rstd, gamma.detach(), beta.detach(), ly.act_slope, residual=res)
             saved.append((z, mean, rstd, use_running))

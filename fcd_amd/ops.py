@@ -334,10 +334,10 @@ def instnorm_stats_from_running(rm: torch.Tensor, rv: torch.Tensor, n: int):
     return mean, rstd
 
 
-def instnorm_update_running(rm, rv, mean, varu):
+def instnorm_update_running(rm, rv, mean, varu, groups: int = 1):
     n, c = mean.shape
-    check(L.load().fcd_instnorm_update_running(ptr(rm), ptr(rv), ptr(mean), ptr(varu), n, c, IN_MOMENTUM, stream()),
-          "update_running")
+    check(L.load().fcd_instnorm_update_running(ptr(rm), ptr(rv), ptr(mean), ptr(varu), n, c, int(groups), IN_MOMENTUM,
+                                               stream()), "update_running")
 
 
 def instnorm_apply(z, mean, rstd, gamma, beta, act_slope: float, residual=None, out=None):

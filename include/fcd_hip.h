@@ -161,9 +161,11 @@ int fcd_instnorm_stats(const float* z, float* mean, float* rstd, float* var_unbi
 /* eval mode of a tracked norm: mean/rstd broadcast from the running buffers. */
 int fcd_instnorm_stats_from_running(const float* running_mean, const float* running_var,
                                     float* mean, float* rstd, int N, int C, float eps, void* stream);
-/* running = (1-m)*running + m*batch-mean of (mean | unbiased var). */
+/* running = (1-m)*running + m*batch-mean of (mean | unbiased var).  groups > 1: the N samples are
+ * `groups` consecutive reference calls of N/groups samples each (paired batches): one momentum
+ * update per group, in order, as the separate calls would make them. */
 int fcd_instnorm_update_running(float* running_mean, float* running_var, const float* mean,
-                                const float* var_unbiased, int N, int C, float momentum,
+                                const float* var_unbiased, int N, int C, int groups, float momentum,
                                 void* stream);
 /* y = act((z-mean)*rstd*gamma + beta) (+ residual); relu: act_slope 0, lrelu: 0.01, none: 1;
  * FCD_ACT_SILU / FCD_ACT_MISH in place of a slope select nn.SiLU / nn.Mish
