@@ -40,6 +40,24 @@ def is_dominant(d):
     return None
 
 
+def engine_clock_mhz(dev):
+    """Current engine clock of `dev` from sysfs (amdgpu's pp_dpm_sclk marks the current level with '*'),
+    matched by PCI address; None when the file is not there or not readable."""
+    import glob
+    try:
+        p = torch.cuda.get_device_properties(dev)
+        bdf = "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+        for d in glob.glob("/sys/class/drm/card*/device"):
+            if os.path.basename(os.path.realpath(d)) != bdf:
+                continue
+            for line in open(os.path.join(d, "pp_dpm_sclk")).read().splitlines():
+                if line.strip().endswith("*"):
+                    return int(line.split(":")[1].strip().split("Mhz")[0])
+    except Exception:
+        pass
+    return None
+
+
 def dominant_kernel_roofline(precision, dev, in_step_us=None, in_step_launches=0, iters=20, symbol=None):
     """The hottest kernel: 3x3 s1 256->256 conv at 32x32 on 32 samples (the G step pairs the reference's
     B=16 generator calls; forward form; dgrad runs the same kernel with flipped taps).  FLOPs per launch
@@ -65,6 +83,16 @@ def dominant_kernel_roofline(precision, dev, in_step_us=None, in_step_launches=0
     e1.record()
     torch.cuda.synchronize()
     loop_us = e0.elapsed_time(e1) / iters * 1e3
+    # engine clock while this kernel runs back to back: queue ~1 s of launches, read sysfs twice while
+    # they drain (valid only if the queue is still busy afterwards)
+    for _ in range(int(1.0e6 / max(loop_us, 20.0))):
+        ops.conv_gather(d, x, wf, out=out)
+    e1.record()        # (the enqueue loop itself blocks on the full queue for a few 100 ms: the card is warm by now)
+    clk = [engine_clock_mhz(dev)]
+    time.sleep(0.05)
+    clk.append(engine_clock_mhz(dev))
+    sclk = None if (e1.query() or None in clk) else sum(clk) // 2
+    torch.cuda.synchronize()
     ms = (in_step_us if in_step_us else loop_us) * 1e-3
     flops = 2.0 * n * 256 * 256 * 9 * h * w
     achieved = flops / (ms * 1e-3) / 1e12
@@ -98,7 +126,11 @@ def dominant_kernel_roofline(precision, dev, in_step_us=None, in_step_launches=0
             "timed": "HIP events around every launch of this kernel in 2 training steps run right after the timed "
                      "region (an event pair per launch slows the step ~14 %, so they stay out of `value`)" if in_step_us
             else "back-to-back loop", "us_per_launch_back_to_back_loop": round(loop_us, 2),
-            "gflop_per_launch": round(flops / 1e9, 3), "traffic": traffic,
+            "gflop_per_launch": round(flops / 1e9, 3),
+            "engine_clock_mhz_under_kernel": sclk, "engine_clock_mhz_nominal": 2400,
+            "clock_note": "sysfs pp_dpm_sclk while this kernel runs back to back; the peaks above assume 2400 MHz, "
+                          "so frac at the clock the card actually holds is frac * 2400 / engine_clock_mhz_under_kernel",
+            "traffic": traffic,
             "traffic_unit": "HBM-side bytes per launch (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; profiles/)"}
 
 

@@ -153,8 +153,9 @@ __device__ __forceinline__ void split3(const f32x8 f, bf16x8_t& h, bf16x8_t& m, 
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
-  static_assert(N >= 0 && N <= 16, "vmcnt immediate");
-  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  static_assert(N >= 0 && N <= 63, "vmcnt immediate");
+  if constexpr (N > 16) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+  else if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
   else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
   else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
