@@ -390,8 +390,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  f32x16 acc2[PREC == FCD_PREC_BF16X3 ? TM : 1][PREC == FCD_PREC_BF16X3 ? TN : 1];   // small terms (BF16X3)
-  if constexpr (PREC == FCD_PREC_BF16X3) {
+  constexpr bool TWOACC = PREC == FCD_PREC_BF16X3;
+  f32x16 acc2[TWOACC ? TM : 1][TWOACC ? TN : 1];   // small terms (BF16X3)
+  if constexpr (TWOACC) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -407,7 +408,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
   const int lr = lane & 31, lh = lane >> 5;
   const int lr16 = lane & 15, lg = lane >> 4;
 
-  if constexpr (PREC == FCD_PREC_BF16X3 && !N16 && S == 3) {
+  if constexpr (PREC == FCD_PREC_BF16X3 && !N16 && (S == 3 || S == 2)) {
     // Software-pipelined BF16X3 loop: the split of k16-step i+1 (VALU) is issued among the MFMAs of
     // step i, so the two pipes overlap inside a wave instead of alternating.  Tiles are fetched three
     // ahead; the one barrier per K-tile sits between the two k16-steps: by then every wave has read
@@ -458,24 +459,24 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
           }
     };
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {
+    for (int s = 0; s < S; ++s) {
       issue_prepare(s, s < nk);
 #pragma unroll
       for (int q = 0; q < ND; ++q) issue_one(q);
       issue_advance();
     }
     Pieces P0, P1;
-    wait_vmcnt<2 * ND>();
+    wait_vmcnt<(S - 1) * ND>();
     __builtin_amdgcn_s_barrier();
     load_split(0, 0, P0);
     int stage = 0;
     for (int it = 0; it < nk; ++it) {
-      const int next = stage == 2 ? 0 : stage + 1;
+      const int next = stage == S - 1 ? 0 : stage + 1;
       load_split(stage, 1, P1);         // VALU under ...
       mfma_phase(P0, false);            // ... the MFMAs of step 0
-      wait_vmcnt<ND>();                 // tile it+1 landed (tile it+2 may fly)
+      wait_vmcnt<(S - 2) * ND>();       // tile it+1 landed (S = 3: tile it+2 may fly)
       __builtin_amdgcn_s_barrier();     // every wave is done reading tile it
-      issue_prepare(stage, it + 3 < nk);
+      issue_prepare(stage, it + S < nk);
       load_split(next, 0, P0);          // first step of tile it+1 (zeros past the end) under ...
       mfma_phase(P1, true);             // ... the MFMAs of step 1, with the DMA of tile it+3 among them
       issue_advance();
@@ -647,7 +648,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
     nstage = nstage + 1 == S ? 0 : nstage + 1;
   }
   }
-  if constexpr (PREC == FCD_PREC_BF16X3) {
+  if constexpr (TWOACC) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1381,6 +1382,16 @@ bool wants_split_weights(const FcdConvDesc* d) {
   return bm == 128 && (bn == 128 || bn == 64);
 }
 
+// The pre-split kernel on a 256x128 tile (4 x 2 waves of 64x64, two-stage ring: 114 KB of LDS) when that
+// still gives every CU a workgroup.  The BF16X3 kernels are power-limited: per MFMA
+// this tile moves 30 % fewer bytes into LDS and reads 37 % fewer out of it than the 128x128 one, the card
+// holds a higher clock, and the 32-sample residual-block convolution takes 185 instead of 201 us.
+bool gather_big_tile(const FcdConvDesc* d) {
+  if (!wants_split_weights(d) || d->Cout < 128 || resolve_splitk(d) != 1) return false;
+  const long M = (long)d->N * d->GH * d->GW;
+  return (long)fcd_cdiv(M, 256) * fcd_cdiv(d->Cout, 128) * d->nphase >= 256;
+}
+
 int run_gather(const FcdConvDesc* d, GatherArgs& a, hipStream_t st) {
   int bm, bn, rc;
   gather_tile(d, bm, bn);
@@ -1390,7 +1401,12 @@ int run_gather(const FcdConvDesc* d, GatherArgs& a, hipStream_t st) {
     a.w_phase_stride = (long)d->Cout * a.K * 3 / 2;      // three bf16 planes, in units of 4 bytes
     dim3 grid(a.tiles_m * a.tiles_n, a.nphase * a.splitk);
     const unsigned in_bytes = (unsigned)((size_t)a.N * a.IH * a.IW * a.Cin * 4), w_bytes = (unsigned)((size_t)a.Cout * a.K * 6);
-    if (bn == 128)
+    if (gather_big_tile(d)) {
+      a.tiles_m = fcd_cdiv(a.M, 256);
+      grid = dim3(a.tiles_m * a.tiles_n, a.nphase * a.splitk);
+      hipLaunchKernelGGL((conv_gather_dma_kernel<256, 128, 4, 2, 2, FCD_PREC_BF16X3, false, true>), grid, dim3(512), 0, st, a,
+                         in_bytes, w_bytes);
+    } else if (bn == 128)
       hipLaunchKernelGGL((conv_gather_dma_kernel<128, 128, 4, 2, 3, FCD_PREC_BF16X3, false, true>), grid, dim3(512), 0, st, a,
                          in_bytes, w_bytes);
     else
@@ -1434,7 +1450,7 @@ int fused_stats_chunks(const FcdConvDesc* d) {
   int bm, bn;
   gather_tile(d, bm, bn);
   if (bn == 16 || resolve_splitk(d) != 1) return 0;
-  const int wtm = wants_split_weights(d) ? 32 : gather_wave_rows(bm, bn);   // the pre-split kernel runs 4 x 2 waves
+  const int wtm = gather_big_tile(d) ? 64 : wants_split_weights(d) ? 32 : gather_wave_rows(bm, bn);   // the pre-split kernel runs 4 x 2 waves
   const long ghw = (long)d->GH * d->GW;
   if (ghw % wtm) return 0;
   return (int)(d->nphase * (ghw / wtm));

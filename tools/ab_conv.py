@@ -15,6 +15,8 @@ x = torch.randn(n, h, w, 256, device=dev); wt = torch.randn(256, 256, 3, 3, devi
 d = g.fwd_desc(n, h, w, precision=2)
 wf = ops.pack_weight_fwd_x3(wt, g)
 out = ops.conv_gather(d, x, wf)
+ref = ops.conv_gather(g.fwd_desc(n, h, w, precision=0), x, ops.pack_weight_fwd(wt, g))
+err = float((out - ref).norm() / ref.norm())
 for _ in range(200): ops.conv_gather(d, x, wf, out=out)
 res = []
 for rep in range(5):
@@ -23,7 +25,7 @@ for rep in range(5):
     for _ in range(100): ops.conv_gather(d, x, wf, out=out)
     e1.record(); torch.cuda.synchronize()
     res.append(round(e0.elapsed_time(e1) * 10, 1))
-print(res)
+print(res, 'rel diff to the exact-fp32 kernel', err)
 ''' % root
 for rnd in range(2):
     for lib in libs:
