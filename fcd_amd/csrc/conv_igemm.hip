@@ -1382,14 +1382,18 @@ bool wants_split_weights(const FcdConvDesc* d) {
   return bm == 128 && (bn == 128 || bn == 64);
 }
 
-// The pre-split kernel on a 256x128 tile (4 x 2 waves of 64x64, two-stage ring: 114 KB of LDS) when that
-// still gives every CU a workgroup.  The BF16X3 kernels are power-limited: per MFMA
-// this tile moves 30 % fewer bytes into LDS and reads 37 % fewer out of it than the 128x128 one, the card
-// holds a higher clock, and the 32-sample residual-block convolution takes 185 instead of 201 us.
+// The pre-split kernel on 256-row tiles when that still gives every CU a workgroup: 256x128 (4 x 2 waves of
+// 64x64, two-stage ring: 114 KB of LDS) or, for <= 64 output channels, 256x64 (8 x 1 waves of 32x64, three
+// stages: 146 KB; no activation fragment is split twice).  The BF16X3 kernels are power-limited (DESIGN.md
+// section 6): per MFMA the 256x128 tile moves 30 % fewer bytes into LDS and reads 37 % fewer out of it than
+// the 128x128 one, the card holds a higher clock, and the 32-sample residual-block convolution takes 185
+// instead of 201 us; the 32-sample 128->64 up-sampling adjoint 221 instead of 265 us.
 bool gather_big_tile(const FcdConvDesc* d) {
-  if (!wants_split_weights(d) || d->Cout < 128 || resolve_splitk(d) != 1) return false;
+  if (!wants_split_weights(d) || resolve_splitk(d) != 1) return false;
+  int bm, bn;
+  gather_tile(d, bm, bn);
   const long M = (long)d->N * d->GH * d->GW;
-  return (long)fcd_cdiv(M, 256) * fcd_cdiv(d->Cout, 128) * d->nphase >= 256;
+  return (long)fcd_cdiv(M, 256) * fcd_cdiv(d->Cout, bn) * d->nphase >= 256;
 }
 
 int run_gather(const FcdConvDesc* d, GatherArgs& a, hipStream_t st) {
@@ -1404,11 +1408,16 @@ int run_gather(const FcdConvDesc* d, GatherArgs& a, hipStream_t st) {
     if (gather_big_tile(d)) {
       a.tiles_m = fcd_cdiv(a.M, 256);
       grid = dim3(a.tiles_m * a.tiles_n, a.nphase * a.splitk);
-      hipLaunchKernelGGL((conv_gather_dma_kernel<256, 128, 4, 2, 2, FCD_PREC_BF16X3, false, true>), grid, dim3(512), 0, st, a,
-                         in_bytes, w_bytes);
+      if (bn == 128)
+        hipLaunchKernelGGL((conv_gather_dma_kernel<256, 128, 4, 2, 2, FCD_PREC_BF16X3, false, true>), grid, dim3(512), 0, st, a,
+                           in_bytes, w_bytes);
+      else
+        hipLaunchKernelGGL((conv_gather_dma_kernel<256, 64, 8, 1, 3, FCD_PREC_BF16X3, false, true>), grid, dim3(512), 0, st, a,
+                           in_bytes, w_bytes);
     } else if (bn == 128)
       hipLaunchKernelGGL((conv_gather_dma_kernel<128, 128, 4, 2, 3, FCD_PREC_BF16X3, false, true>), grid, dim3(512), 0, st, a,
                          in_bytes, w_bytes);
+
     else
       hipLaunchKernelGGL((conv_gather_dma_kernel<128, 64, 4, 2, 3, FCD_PREC_BF16X3, false, true>), grid, dim3(512), 0, st, a,
                          in_bytes, w_bytes);
@@ -1450,7 +1459,8 @@ int fused_stats_chunks(const FcdConvDesc* d) {
   int bm, bn;
   gather_tile(d, bm, bn);
   if (bn == 16 || resolve_splitk(d) != 1) return 0;
-  const int wtm = gather_big_tile(d) ? 64 : wants_split_weights(d) ? 32 : gather_wave_rows(bm, bn);   // the pre-split kernel runs 4 x 2 waves
+  // rows per wave: the pre-split kernels run 4 x 2 waves on 128 rows, 4 x 2 or 8 x 1 on 256
+  const int wtm = (gather_big_tile(d) && bn == 128) ? 64 : wants_split_weights(d) ? 32 : gather_wave_rows(bm, bn);
   const long ghw = (long)d->GH * d->GW;
   if (ghw % wtm) return 0;
   return (int)(d->nphase * (ghw / wtm));

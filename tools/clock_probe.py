@@ -1,8 +1,10 @@
-"""Engine clock and socket power while the residual-block convolution (fp32x3, 32 samples) runs back to
-back for a few seconds: a child process loops the kernel, this process polls rocm-smi (read-only)."""
+"""Engine clock while the residual-block convolution (32 samples) runs back to back for a few seconds: a
+child process loops the kernel, this process polls rocm-smi (read-only).
+    python tools/clock_probe.py <precision 0|1|2> [wgrad]"""
 import os, subprocess, sys, time
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 prec = sys.argv[1] if len(sys.argv) > 1 else "2"
+wgrad = len(sys.argv) > 2 and sys.argv[2] == "wgrad"
 code = r'''
 import sys, time, torch
 sys.path.insert(0, %r)
@@ -13,14 +15,21 @@ x = torch.randn(32, 32, 32, 256, device=dev); wt = torch.randn(256, 256, 3, 3, d
 prec = %s
 d = g.fwd_desc(32, 32, 32, precision=prec)
 wf = ops.pack_weight_fwd_x3(wt, g) if prec == 2 else ops.pack_weight_fwd(wt, g)
-out = ops.conv_gather(d, x, wf)
+if %s:
+    gy = torch.randn(32, 32, 32, 256, device=dev)
+    wd = g.wgrad_desc(32, 32, 32, precision=prec)
+    dw = ops.conv_wgrad(wd, gy, x)
+    run = lambda: ops.conv_wgrad(wd, gy, x, dw)
+else:
+    out = ops.conv_gather(d, x, wf)
+    run = lambda: ops.conv_gather(d, x, wf, out=out)
 torch.cuda.synchronize(); print("go", flush=True)
 t0 = time.time(); n = 0
 while time.time() - t0 < 8:
-    for _ in range(500): ops.conv_gather(d, x, wf, out=out)
+    for _ in range(500): run()
     torch.cuda.synchronize(); n += 500
 print("us per launch", (time.time() - t0) / n * 1e6, flush=True)
-''' % (root, prec)
+''' % (root, prec, wgrad)
 child = subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, text=True)
 print(child.stdout.readline().strip(), flush=True)
 for i in range(7):
