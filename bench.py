@@ -29,13 +29,19 @@ PEAK_TFLOPS = {"fp32": 157.3, "fp32x3": 157.3, "bf16": 2500.0}   # MI355X_MICROA
 
 def is_dominant(d):
     """Tag for ops.KernelTimer.  'dominant': the hottest launch, 3x3 s1 256->256 conv at 32x32 on the
-    G step's paired batch of 2 x 16 samples (residual blocks, forward and dgrad).  'symbol': every other launch that runs the same kernel
-    symbol (the 128x128-tile gather kernel: Cout > 64 and more than 64 output pixels per phase) --
-    rocprofv3's per-kernel average is over all of these."""
+    G step's paired batch of 2 x 16 samples (residual blocks, forward and dgrad).  'symbol': every other
+    launch that runs the same kernel symbol -- rocprofv3's per-kernel average is over all of these.  In
+    fp32x3 that is the 256x128-tile pre-split gather kernel (more than 64 output channels, 32-channel
+    K slices, a grid of at least 256 such tiles: csrc/conv_igemm.hip gather_big_tile); in the other
+    precisions the 128x128-tile kernel (Cout > 64 and more than 64 output pixels per phase)."""
     if (d.Cin == 256 and d.Cout == 256 and d.KH == 3 and d.KW == 3 and d.IH == 32 and d.IW == 32
             and d.N == 2 * BASE["batch"] and d.nphase == 1):
         return "dominant"      # the G step runs the generator on paired batches (2 x 16 samples per call)
-    if d.Cout > 64 and d.N * d.GH * d.GW > 64:
+    m = d.N * d.GH * d.GW
+    if d.precision == 2:       # FCD_PREC_BF16X3
+        big = -(-m // 256) * -(-d.Cout // 128) * d.nphase >= 256
+        return "symbol" if (d.Cout > 64 and d.Cin % 32 == 0 and big) else None
+    if d.Cout > 64 and m > 64:
         return "symbol"
     return None
 
@@ -108,19 +114,21 @@ def dominant_kernel_roofline(precision, dev, in_step_us=None, in_step_launches=0
         extra = {"executed_bf16_tflops": round(6 * achieved, 1), "fp32_mfma_peak": PEAK_TFLOPS["fp32"],
                  "note": "algorithmic fp32 FLOPs; peak = dense bf16 MFMA peak / 6 (six bf16 MFMAs per fp32 product group); "
                          "the exact-fp32 MFMA pipe peaks at 157.3"}
-        # profiles/r1_p_resblock_conv_x3_b32_pmc_*.csv: FETCH_SIZE 44168 KB x 2 + WRITE_SIZE 32768 KB (the
-        # weights travel as three bf16 planes: 3.5 MB instead of 2.4 MB per XCD)
-        traffic = 2 * 44168 * 1024 + 32768 * 1024
+        # profiles/r1_r_resblock_conv_x3_b32_tile256_pmc_*.csv (256x128 tile): FETCH_SIZE 30682 KB x 2 +
+        # WRITE_SIZE 33280 KB (the 128x128 tile read 44168 KB x 2: twice as many workgroups re-read the
+        # activation halo rows and the three weight planes)
+        traffic = 2 * 30682 * 1024 + 33280 * 1024
     if symbol is not None:
         # all launches of the same kernel symbol in the instrumented steps (what rocprofv3 --stats averages)
         cnt, us, fl = symbol
         extra["kernel_symbol_all_shapes"] = {
             "launches_per_step": cnt // 2, "avg_us_per_launch": round(us / max(1, cnt), 2),
             "achieved": round(fl / (us * 1e-6) / 1e12, 2), "frac": round(fl / (us * 1e-6) / 1e12 / peak, 4),
-            "note": "every launch of conv_gather_dma_kernel<128,128,...> in 2 training steps (all layer shapes; "
+            "note": "every launch of this kernel symbol in 2 training steps (all layer shapes; "
                     "launches with fused InstanceNorm statistics include their ~6 us finalize kernel): compare "
                     "with the per-kernel average of profiles/*_kernel_stats.csv"}
-    return {**extra, "bound": "mfma", "kernel": "conv_gather_dma_kernel<128,128> 3x3 256->256 @32x32, 32 samples per launch (two paired B=16 calls)",
+    return {**extra, "bound": "mfma", "kernel": ("conv_gather_dma_kernel<256,128,4,2,2,BF16X3,pre-split weights>" if precision == "fp32x3" else
+                                          "conv_gather_dma_kernel<128,128>") + " 3x3 256->256 @32x32, 32 samples per launch (two paired B=16 calls)",
             "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
             "us_per_launch": round(ms * 1e3, 2), "launches_timed": in_step_launches,
             "timed": "HIP events around every launch of this kernel in 2 training steps run right after the timed "
