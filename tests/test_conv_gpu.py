@@ -193,3 +193,54 @@ def test_wgrad_7x7_halo(dev, geom, prec):
     d2.splitk = 3
     dw3 = ops.conv_wgrad(d2, gyd, xd)
     assert relerr(dw3.cpu(), dw.cpu()) <= 1e-5
+
+
+# 256-row BF16X3 gather tiles (csrc/conv_igemm.hip gather_big_tile: chosen when the grid still has >= 256
+# workgroups).  Samples are independent, so a launch on all samples (256-row tiles) must give the same bits
+# as launches on slices small enough to take the 128-row tiles -- and both must meet the fp32 bar against
+# torch.  The slices are sized to stay above the split-K threshold (>= 192 tiles of 128 rows) and below
+# the 256-row one.  (O, I, k, s, p, N, H, W, form, slice)
+BIG_TILE_GEOMS = [
+    (256, 256, 3, 1, 1, 32, 32, 32, "fwd", 16),     # residual-block conv: 256x128 tile, 256 workgroups
+    (256, 256, 3, 1, 1, 40, 30, 30, "fwd", 20),     # ragged: M = 36000 is not a multiple of 256
+    (256, 128, 4, 2, 1, 40, 60, 60, "fwd", 20),     # strided down-sampling, ragged
+    (128, 64, 4, 2, 1, 18, 62, 62, "adj", 2),       # 128 -> 64 up-sampling adjoint: 256x64 tile, four phases, ragged
+    (64, 64, 3, 1, 1, 18, 62, 62, "fwd", 9),        # 64 output channels, one phase: 256x64 tile
+]
+
+
+@pytest.mark.parametrize("geom", BIG_TILE_GEOMS)
+def test_big_tile_equals_small_tile(dev, geom):
+    from fcd_amd import ops
+    O, I, k, s, p, N, H, W, form, step = geom
+    g = ops.ConvGeom(O, I, k, s, p)
+    torch.manual_seed(7)
+    w = torch.randn(O, I, k, k) / (I * k * k) ** 0.5
+    b = torch.randn(O if form == "fwd" else I)
+    if form == "fwd":
+        xc = torch.randn(N, I, H, W)
+        ref = F.leaky_relu(F.conv2d(xc, w, b, s, p), 0.01)
+        x = to_nhwc(xc, g.IP).to(dev)
+        desc = lambda n: g.fwd_desc(n, H, W, precision=2, act_slope=0.01)
+        cout = O
+    else:
+        xc = torch.randn(N, O, H, W)
+        ref = F.leaky_relu(F.conv_transpose2d(xc, w, b, s, p), 0.01)
+        x = to_nhwc(xc, g.OP).to(dev)
+        desc = lambda n: g.adj_desc(n, H, W, precision=2, act_slope=0.01)
+        cout = I
+    wp = pack_for(desc(N), w.to(dev), g, form)
+    full = ops.conv_gather(desc(N), x, wp, bias=b.to(dev))
+    assert relerr(from_nhwc(full.cpu(), cout), ref) <= TOL[2]
+    for i in range(0, N, step):
+        part = ops.conv_gather(desc(step), x[i:i + step].contiguous(), wp, bias=b.to(dev))
+        assert torch.equal(part, full[i:i + step]), i
+    if form == "fwd" and s == 1:
+        # fused InstanceNorm statistics on the 256-row tiles (64 / 32 rows per wave)
+        d = g.fwd_desc(N, H, W, precision=2)
+        z0 = ops.conv_gather(d, x, wp)
+        z1, m1, r1, v1 = ops.conv_gather_stats(d, x, wp, want_var=True)
+        assert torch.equal(z0, z1)
+        zc = z1.cpu().double()
+        assert relerr(m1, zc.mean((1, 2))) <= 1e-5
+        assert relerr(v1, zc.var((1, 2), unbiased=True)) <= 1e-5
