@@ -1162,6 +1162,105 @@ __global__ __launch_bounds__(64 * H7_WAVES) void wgrad7_halo_kernel(const WgradA
   }
 }
 
+// Forward form of the same idea: a 7x7, stride-1, pad-3 convolution from 64 channels to at most 16 (the
+// generator's last layer, 64 -> 10 at 128x128).  The generic 16-wide gather kernel streams the input once
+// per tap through L2 -> LDS (49 x 134 MB per 32-sample launch), which is what bounds it at about three times
+// its MFMA floor.  Here a workgroup owns (image, 32-column strip, row range) and keeps the 7 input rows an
+// output row needs in an 8-slot ring of LDS rows (38 pixels x 64 channels, padded to 40): every input row is
+// loaded once.  Each of the 7 waves owns tap row th and holds its 7 x 64 x 16 weights in 112 registers for
+// the whole kernel; per output row it accumulates its taps from shifted reads of the ring
+// (v_mfma_f32_16x16x4_f32: M = 16 pixels, N = 16 output channels, K = 4 channels), the 7 partial tiles are
+// summed through LDS in a fixed order (wave 0 .. 6), and bias / LeakyReLU are applied at the store.
+// LDS row layout [pixel][16 chunks of 4 channels], chunk slot XOR (pixel & 15) applied on the DMA source
+// side, so that the 16 pixels of a fragment read hit 16 distinct bank groups.
+constexpr int F7_CW = 32;     // output columns per workgroup
+constexpr int F7_XW = 40;     // pixels per LDS ring row: 38 used, 10 whole DMA instructions
+__global__ __launch_bounds__(64 * H7_WAVES) void conv7_halo_kernel(const GatherArgs p, const int rows, const int nch,
+                                                                  const unsigned in_bytes) {
+  __shared__ float4 Xs[8 * F7_XW * 16];          // [ring slot][pixel][16 chunks = 64 channels]
+  __shared__ float Rs[2 * H7_WAVES * F7_CW * 16]; // [row parity][wave][pixel][16 output channels]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ch = blockIdx.x % nch, r = blockIdx.x / nch, n = blockIdx.y;
+  const int x0 = ch * F7_CW, y0 = r * rows, y1 = min(p.OH, y0 + rows);
+  const i32x4 rin = make_rsrc(p.in, in_bytes);
+  const unsigned lx = lds_addr_of(Xs);
+  const int dpx = lane >> 4, dslot = lane & 15;      // pixel within a DMA instruction, chunk slot
+
+  // instruction j (0..9) of input row yy -> ring slot (yy & 7)
+  auto issue_x = [&](int j, int yy) {
+    const int px = j * 4 + dpx, gx = x0 - 3 + px;
+    const bool ok = px < F7_CW + 6 && yy >= 0 && yy < p.IH && gx >= 0 && gx < p.IW;
+    const unsigned voff = ok ? (unsigned)((((n * p.IH + yy) * p.IW + gx) * 64 + 4 * (dslot ^ (px & 15))) * 4) : OOB;
+    dma16(rin, voff, lx + (unsigned)((((yy + 16) & 7) * F7_XW * 16 + j * 64) * 16));
+  };
+  auto issue_row = [&](int yy) {
+#pragma unroll
+    for (int q = 0; q < 10; ++q)
+      if (q % H7_WAVES == wave) issue_x(q, yy);
+  };
+  for (int q = wave; q < 7 * 10; q += H7_WAVES) issue_x(q % 10, y0 - 3 + q / 10);   // rows y0-3 .. y0+3
+
+  // this wave's weights: tap row th = wave; lane (co = lane&15, g = lane>>4) holds channels 16c + 4g .. +3
+  const int c16 = lane & 15, g4 = lane >> 4;
+  float4 wreg[28];
+#pragma unroll
+  for (int t = 0; t < 7; ++t)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      wreg[t * 4 + c] = c16 < p.Cout
+          ? *reinterpret_cast<const float4*>(p.w + (long)c16 * p.K + (wave * 7 + t) * 64 + 16 * c + 4 * g4)
+          : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float bs = (p.bias && c16 < p.Cout) ? p.bias[c16] : 0.f;
+  wait_vmcnt<0>();
+  __syncthreads();
+
+  for (int y = y0; y < y1; ++y) {
+    issue_row(y + 4);                        // past the image: out-of-range lanes write zeros
+    const float4* Xrow = Xs + ((y + wave - 3 + 16) & 7) * (F7_XW * 16);
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int t = 0; t < 7; ++t)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          const int P = 16 * mt + c16 + t;
+          const float4 a = Xrow[P * 16 + ((4 * c + g4) ^ (P & 15))];
+          const float4 b = wreg[t * 4 + c];
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc[mt], 0, 0, 0);
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc[mt], 0, 0, 0);
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc[mt], 0, 0, 0);
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc[mt], 0, 0, 0);
+        }
+    // D[pixel = 4*(lane>>4) + e][co = lane&15]
+    float* R = Rs + ((y & 1) * H7_WAVES + wave) * (F7_CW * 16);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) R[(16 * mt + 4 * g4 + e) * 16 + c16] = acc[mt][e];
+    wait_vmcnt<0>();
+    __syncthreads();
+    // fixed-order sum of the 7 tap rows, epilogue, store: thread -> (pixel, co)
+    const float* R0 = Rs + (y & 1) * H7_WAVES * (F7_CW * 16);
+    for (int idx = tid; idx < F7_CW * 16; idx += 64 * H7_WAVES) {
+      const int px = idx >> 4, co = idx & 15;
+      if (x0 + px >= p.OW || co >= p.CoutP) continue;
+      float v = 0.f;
+#pragma unroll
+      for (int w7 = 0; w7 < H7_WAVES; ++w7) v += R0[w7 * (F7_CW * 16) + idx];
+      if (co < p.Cout) {
+        if (p.bias) v += p.bias[co];
+        v = v > 0.f ? v : v * p.act_slope;
+      } else {
+        v = 0.f;
+      }
+      p.out[(((long)n * p.OH + y) * p.OW + x0 + px) * p.CoutP + co] = v;
+    }
+  }
+  (void)bs;
+}
+
 __global__ __launch_bounds__(256) void pack_fwd_kernel(const float* __restrict__ w, float* __restrict__ out,
                                                        int O, int I, int IP, int taps) {
   const long total = (long)O * taps * IP;
@@ -1396,9 +1495,29 @@ bool gather_big_tile(const FcdConvDesc* d) {
   return (long)fcd_cdiv(M, 256) * fcd_cdiv(d->Cout, bn) * d->nphase >= 256;
 }
 
+// The halo form of the 7x7, 64 -> <= 16 channel convolution (conv7_halo_kernel): rows per workgroup, or 0.
+int halo7_fwd_rows(const FcdConvDesc* d, const GatherArgs& a) {
+  if (d->precision == FCD_PREC_BF16 || d->KH != 7 || d->KW != 7 || d->nphase != 1 || d->istride != 1 || d->ostride != 1) return 0;
+  if (d->pad_h[0] != 3 || d->pad_w[0] != 3 || d->Cin != 64 || d->Cout > 16 || d->CoutP > 16) return 0;
+  if (d->GH != d->IH || d->GW != d->IW || d->OH != d->GH || d->OW != d->GW || d->ooff_h[0] || d->ooff_w[0]) return 0;
+  if (a.mask || a.res || a.splitk != 1 || a.stats) return 0;
+  // about two workgroups per CU; a shorter row range only re-loads its 6 halo rows more often
+  const long base = (long)d->N * fcd_cdiv(d->GW, F7_CW);
+  long rr = (256 + base / 2) / base;
+  if (rr > d->GH / 8) rr = d->GH / 8;
+  if (rr < 1) rr = 1;
+  return fcd_cdiv(d->GH, (int)rr);
+}
+
 int run_gather(const FcdConvDesc* d, GatherArgs& a, hipStream_t st) {
   int bm, bn, rc;
   gather_tile(d, bm, bn);
+  if (const int rows = halo7_fwd_rows(d, a)) {
+    const int nch = fcd_cdiv(d->GW, F7_CW), R = fcd_cdiv(d->GH, rows);
+    hipLaunchKernelGGL(conv7_halo_kernel, dim3(nch * R, d->N), dim3(64 * H7_WAVES), 0, st, a, rows, nch,
+                       (unsigned)((size_t)a.N * a.IH * a.IW * a.Cin * 4));
+    return fcd_check_launch("conv7_halo");
+  }
   if (wants_split_weights(d)) {
     a.tiles_m = fcd_cdiv(a.M, 128);
     a.tiles_n = fcd_cdiv(d->Cout, bn);

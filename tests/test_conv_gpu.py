@@ -244,3 +244,33 @@ def test_big_tile_equals_small_tile(dev, geom):
         zc = z1.cpu().double()
         assert relerr(m1, zc.mean((1, 2))) <= 1e-5
         assert relerr(v1, zc.var((1, 2), unbiased=True)) <= 1e-5
+
+
+# 7x7 / 64 input channels / <= 16 output channels: the forward halo kernel (input rows loaded once for all
+# 49 taps).  Ragged widths (strips with out-of-range halo), heights that do not divide into the row ranges,
+# 3 / 10 / 16 output channels, with and without bias.  (O, N, H, W, bias)
+HALO_FWD_GEOMS = [
+    (10, 2, 128, 128, False),
+    (10, 3, 21, 45, True),
+    (3, 1, 40, 33, True),
+    (16, 2, 9, 70, False),
+    (12, 5, 64, 64, True),
+]
+
+
+@pytest.mark.parametrize("prec", [0, 2])
+@pytest.mark.parametrize("geom", HALO_FWD_GEOMS)
+def test_conv_7x7_halo_forward(dev, geom, prec):
+    from fcd_amd import ops
+    O, N, H, W, with_bias = geom
+    g = ops.ConvGeom(O, 64, 7, 1, 3)
+    torch.manual_seed(11)
+    x = torch.randn(N, 64, H, W)
+    w = torch.randn(O, 64, 7, 7) / 56
+    b = torch.randn(O) if with_bias else None
+    ref = F.leaky_relu(F.conv2d(x.double(), w.double(), None if b is None else b.double(), 1, 3), 0.2)
+    xd = to_nhwc(x, g.IP).to(dev)
+    d = g.fwd_desc(N, H, W, precision=prec, act_slope=0.2)
+    out = ops.conv_gather(d, xd, pack_for(d, w.to(dev), g, "fwd"), bias=None if b is None else b.to(dev))
+    assert relerr(from_nhwc(out.cpu(), O).double(), ref) <= TOL[prec]
+    assert float(out[..., O:].abs().max()) == 0.0 if g.OP > O else True     # padded channels stay zero
