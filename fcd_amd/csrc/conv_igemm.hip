@@ -1767,10 +1767,83 @@ extern "C" int fcd_conv_wgrad(const FcdWgradDesc* d, const float* gsmall, const 
   return fcd_check_launch("wgrad_reduce");
 }
 
+// The same two packs for 4x4 kernels (the discriminator's layers hold 42 of the 45 M discriminator weights),
+// arranged so that global reads and writes are both contiguous: the 16 taps of an (o, i) pair are 64
+// contiguous bytes of w, and the element-per-thread kernels above fetch each such line once per tap.
+// Forward form: one thread per (o, i) pair; for a fixed tap consecutive threads write consecutive i.
+template <bool X3>
+__device__ __forceinline__ void store_packed(void* __restrict__ out, long plane_stride, long idx, float v) {
+  if constexpr (X3) store_split3(static_cast<unsigned short*>(out), plane_stride, idx, v);
+  else static_cast<float*>(out)[idx] = v;
+}
+template <bool X3>
+__global__ __launch_bounds__(256) void pack_fwd_taps16_kernel(const float* __restrict__ w, void* __restrict__ out,
+                                                              int O, int I) {
+  const long pairs = (long)O * I, plane = pairs * 16;
+  for (long pidx = (long)blockIdx.x * 256 + threadIdx.x; pidx < pairs; pidx += (long)gridDim.x * 256) {
+    const int i = (int)(pidx % I);
+    const long o = pidx / I;
+    const float4* src = reinterpret_cast<const float4*>(w + pidx * 16);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = src[q];
+      store_packed<X3>(out, plane, (o * 16 + 4 * q + 0) * I + i, v.x);
+      store_packed<X3>(out, plane, (o * 16 + 4 * q + 1) * I + i, v.y);
+      store_packed<X3>(out, plane, (o * 16 + 4 * q + 2) * I + i, v.z);
+      store_packed<X3>(out, plane, (o * 16 + 4 * q + 3) * I + i, v.w);
+    }
+  }
+}
+// Adjoint form (stride 2, four phases): a block moves a 64 (o) x 4 (i) x 16 (taps) tile through LDS: reads
+// run along i and the taps, writes along o.
+template <bool X3>
+__global__ __launch_bounds__(256) void pack_adj_s2_tiled_kernel(const float* __restrict__ w, void* __restrict__ out,
+                                                                int O, int I) {
+  __shared__ float tile[4][16][65];
+  const int nib = I / 4, nblk = (O / 64) * nib;
+  const long per_phase = (long)I * 4 * O;
+  for (int b = blockIdx.x; b < nblk; b += gridDim.x) {
+    const int ob = b / nib, ib = b - ob * nib;
+    {
+      const int o_l = threadIdx.x >> 2, i_l = threadIdx.x & 3;
+      const float4* src = reinterpret_cast<const float4*>(w + ((long)(ob * 64 + o_l) * I + ib * 4 + i_l) * 16);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 v = src[q];
+        tile[i_l][4 * q + 0][o_l] = v.x;
+        tile[i_l][4 * q + 1][o_l] = v.y;
+        tile[i_l][4 * q + 2][o_l] = v.z;
+        tile[i_l][4 * q + 3][o_l] = v.w;
+      }
+    }
+    __syncthreads();
+    {
+      const int o_l = threadIdx.x & 63, i_l = threadIdx.x >> 6;
+      const int o = ob * 64 + o_l, i = ib * 4 + i_l;
+#pragma unroll
+      for (int tap = 0; tap < 16; ++tap) {
+        const int kh = tap >> 2, kw = tap & 3;
+        const int py = (3 - kh) & 1, px = (3 - kw) & 1;      // kh = 3 - py - 2 th
+        const int th = (3 - py - kh) >> 1, tw = (3 - px - kw) >> 1;
+        const int ph = 2 * py + px;
+        const long base = (long)ph * per_phase;
+        if constexpr (X3) store_split3(static_cast<unsigned short*>(out) + 3 * base, per_phase, ((long)(i * 2 + th) * 2 + tw) * O + o, tile[i_l][tap][o_l]);
+        else static_cast<float*>(out)[base + ((long)(i * 2 + th) * 2 + tw) * O + o] = tile[i_l][tap][o_l];
+      }
+    }
+    __syncthreads();
+  }
+}
+
 extern "C" int fcd_pack_weight_fwd(const float* w, float* packed, int O, int I, int IP, int KH, int KW,
                                    void* stream) {
   FCD_REQUIRE(w && packed && O > 0 && I > 0 && IP >= I && IP % 4 == 0 && KH > 0 && KW > 0, "pack_fwd: bad arguments");
   const long total = (long)O * KH * KW * IP;
+  if (KH * KW == 16 && I == IP) {
+    const int tblocks = (int)std::min<long>(fcd_cdiv((long)O * I, 256), 8192);
+    hipLaunchKernelGGL(pack_fwd_taps16_kernel<false>, dim3(tblocks), dim3(256), 0, fcd_stream(stream), w, packed, O, I);
+    return fcd_check_launch("pack_fwd");
+  }
   const int blocks = (int)std::min<long>(fcd_cdiv(total, 256), 4096);
   hipLaunchKernelGGL(pack_fwd_kernel, dim3(blocks), dim3(256), 0, fcd_stream(stream), w, packed, O, I, IP, KH * KW);
   return fcd_check_launch("pack_fwd");
@@ -1783,6 +1856,11 @@ extern "C" int fcd_conv_wants_split_weights(const FcdConvDesc* d) {
 extern "C" int fcd_pack_weight_fwd_x3(const float* w, void* packed, int O, int I, int IP, int KH, int KW, void* stream) {
   FCD_REQUIRE(w && packed && O > 0 && I > 0 && IP >= I && IP % 4 == 0 && KH > 0 && KW > 0, "pack_weight_fwd_x3: bad arguments");
   const long total = (long)O * KH * KW * IP;
+  if (KH * KW == 16 && I == IP) {
+    const int blocks = (int)std::min<long>(fcd_cdiv((long)O * I, 256), 8192);
+    hipLaunchKernelGGL(pack_fwd_taps16_kernel<true>, dim3(blocks), dim3(256), 0, fcd_stream(stream), w, packed, O, I);
+    return fcd_check_launch("pack_weight_fwd_x3");
+  }
   const int blocks = (int)std::min<long>(fcd_cdiv(total, 256), 4096);
   hipLaunchKernelGGL(pack_fwd_x3_kernel, dim3(blocks), dim3(256), 0, fcd_stream(stream), w, (unsigned short*)packed, O, I,
                      IP, KH * KW);
@@ -1795,6 +1873,11 @@ extern "C" int fcd_pack_weight_adj_x3(const float* w, void* packed, int O, int O
   FCD_REQUIRE((stride == 1) || (stride == 2 && KH == 4 && KW == 4), "pack_weight_adj_x3: unsupported stride/kernel");
   const int TH = stride == 1 ? KH : 2, TW = stride == 1 ? KW : 2, nph = stride == 1 ? 1 : 4;
   const long total = (long)nph * I * TH * TW * OP;
+  if (stride == 2 && O == OP && O % 64 == 0 && I % 4 == 0) {
+    const int blocks = (int)std::min<long>((long)(O / 64) * (I / 4), 8192);
+    hipLaunchKernelGGL(pack_adj_s2_tiled_kernel<true>, dim3(blocks), dim3(256), 0, fcd_stream(stream), w, packed, O, I);
+    return fcd_check_launch("pack_weight_adj_x3");
+  }
   const int blocks = (int)std::min<long>(fcd_cdiv(total, 256), 4096);
   hipLaunchKernelGGL(pack_adj_x3_kernel, dim3(blocks), dim3(256), 0, fcd_stream(stream), w, (unsigned short*)packed, O, OP,
                      I, KH, KW, stride);
@@ -1807,6 +1890,11 @@ extern "C" int fcd_pack_weight_adj(const float* w, float* packed, int O, int OP,
   FCD_REQUIRE(stride == 1 || (stride == 2 && KH == 4 && KW == 4), "pack_adj: stride %d with %dx%d taps unsupported", stride, KH, KW);
   const int TH = stride == 1 ? KH : 2, TW = stride == 1 ? KW : 2, nph = stride == 1 ? 1 : 4;
   const long total = (long)nph * I * TH * TW * OP;
+  if (stride == 2 && O == OP && O % 64 == 0 && I % 4 == 0) {
+    const int tblocks = (int)std::min<long>((long)(O / 64) * (I / 4), 8192);
+    hipLaunchKernelGGL(pack_adj_s2_tiled_kernel<false>, dim3(tblocks), dim3(256), 0, fcd_stream(stream), w, packed, O, I);
+    return fcd_check_launch("pack_adj");
+  }
   const int blocks = (int)std::min<long>(fcd_cdiv(total, 256), 4096);
   hipLaunchKernelGGL(pack_adj_kernel, dim3(blocks), dim3(256), 0, fcd_stream(stream), w, packed, O, OP, I, KH, KW, stride);
   return fcd_check_launch("pack_adj");
