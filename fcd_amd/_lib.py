@@ -75,6 +75,7 @@ PROTOTYPES = {
     "fcd_instnorm_stats": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _P, _Z, _P]),
     "fcd_instnorm_stats_from_running": (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),
     "fcd_instnorm_update_running": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _P]),
+    "fcd_instnorm_update_running_batch": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "fcd_instnorm_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P]),
     "fcd_instnorm_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P, _Z, _P]),
     "fcd_g_prologue": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),

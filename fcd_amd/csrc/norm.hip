@@ -364,6 +364,56 @@ extern "C" int fcd_instnorm_stats_from_running(const float* running_mean, const 
   return fcd_check_launch("stats_from_running");
 }
 
+namespace {
+struct RunningBatch {
+  float* rm[FCD_RUNNING_BATCH_MAX];
+  float* rv[FCD_RUNNING_BATCH_MAX];
+  const float* mean[FCD_RUNNING_BATCH_MAX];
+  const float* varu[FCD_RUNNING_BATCH_MAX];
+};
+// blockIdx.y = norm; same arithmetic, in the same order, as update_running_kernel
+__global__ __launch_bounds__(256) void update_running_batch_kernel(const RunningBatch b, int N, int C, int groups,
+                                                                   float momentum) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float* __restrict__ rm = b.rm[blockIdx.y];
+  float* __restrict__ rv = b.rv[blockIdx.y];
+  const float* __restrict__ mean = b.mean[blockIdx.y];
+  const float* __restrict__ varu = b.varu[blockIdx.y];
+  const int gn = N / groups;
+  float m = rm[c], v = rv[c];
+  for (int g = 0; g < groups; ++g) {
+    float sm = 0.f, sv = 0.f;
+    for (int n = g * gn; n < (g + 1) * gn; ++n) {
+      sm += mean[(long)n * C + c];
+      sv += varu[(long)n * C + c];
+    }
+    m = (1.f - momentum) * m + momentum * (sm / (float)gn);
+    v = (1.f - momentum) * v + momentum * (sv / (float)gn);
+  }
+  rm[c] = m;
+  rv[c] = v;
+}
+}  // namespace
+
+extern "C" int fcd_instnorm_update_running_batch(float* const* running_mean, float* const* running_var,
+                                                 const float* const* mean, const float* const* var_unbiased,
+                                                 int count, int N, int C, int groups, float momentum, void* stream) {
+  FCD_REQUIRE(running_mean && running_var && mean && var_unbiased, "update_running_batch: null array");
+  FCD_REQUIRE(count >= 1 && count <= FCD_RUNNING_BATCH_MAX, "update_running_batch: count %d not in 1..%d", count,
+              FCD_RUNNING_BATCH_MAX);
+  FCD_REQUIRE(N > 0 && C > 0 && groups >= 1 && N % groups == 0, "update_running_batch: bad N / C / groups");
+  RunningBatch b;
+  for (int i = 0; i < FCD_RUNNING_BATCH_MAX; ++i) {
+    const int j = i < count ? i : 0;
+    FCD_REQUIRE(running_mean[j] && running_var[j] && mean[j] && var_unbiased[j], "update_running_batch: null tensor");
+    b.rm[i] = running_mean[j]; b.rv[i] = running_var[j]; b.mean[i] = mean[j]; b.varu[i] = var_unbiased[j];
+  }
+  hipLaunchKernelGGL(update_running_batch_kernel, dim3(fcd_cdiv(C, 256), count), dim3(256), 0, fcd_stream(stream), b, N, C,
+                     groups, momentum);
+  return fcd_check_launch("update_running_batch");
+}
+
 extern "C" int fcd_instnorm_update_running(float* running_mean, float* running_var, const float* mean,
                                            const float* var_unbiased, int N, int C, int groups, float momentum,
                                            void* stream) {

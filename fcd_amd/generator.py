@@ -236,6 +236,7 @@ class _GeneratorFn(torch.autograd.Function):
         cp = plan[0].geom.IP
         acts = [ops.g_prologue(x, c, cp)]      # acts[i] = input of layer i
         saved = []                              # per layer: (z, mean, rstd, use_running)
+        running = {}                            # (N, C) -> tracked norms whose running statistics this call updates
         pi = 0
         for li, ly in enumerate(plan):
             wt = params[pi]
@@ -273,12 +274,15 @@ class _GeneratorFn(torch.autograd.Function):
             if use_running:
                 mean, rstd = ops.instnorm_stats_from_running(nm.running_mean, nm.running_var, n)
             elif nm.track:
-                # one momentum update per reference call (sample group), in call order
-                ops.instnorm_update_running(nm.running_mean, nm.running_var, mean, varu, groups=mod._groups)
+                # one momentum update per reference call (sample group), in call order; the norms of equal
+                # width go out in one launch after the layer loop
+                running.setdefault(mean.shape, []).append((nm.running_mean, nm.running_var, mean, varu))
             res = acts[li + 1 + ly.res_from] if ly.res_from is not None else None
             y = ops.instnorm_apply(z, mean, rstd, gamma.detach(), beta.detach(), ly.act_slope, residual=res)
             saved.append((z, mean, rstd, use_running))
             acts.append(y)
+        for items in running.values():
+            ops.instnorm_update_running_batch(items, groups=mod._groups)
         x_fake = ops.g_epilogue_fwd(acts[-1], x)
         ctx.mod = mod
         ctx.acts = acts

@@ -340,6 +340,24 @@ def instnorm_update_running(rm, rv, mean, varu, groups: int = 1):
                                                stream()), "update_running")
 
 
+RUNNING_BATCH_MAX = 16
+
+
+def instnorm_update_running_batch(items, groups: int = 1) -> None:
+    """One launch for the momentum updates of several tracked norms of one generator call: ``items`` is a
+    list of (running_mean, running_var, mean, var_unbiased) with equal (N, C)."""
+    import ctypes
+    for i in range(0, len(items), RUNNING_BATCH_MAX):
+        part = items[i:i + RUNNING_BATCH_MAX]
+        n, c = part[0][2].shape
+        if any(it[2].shape != (n, c) for it in part):
+            raise RuntimeError("instnorm_update_running_batch: norms of different (N, C) in one batch")
+        arr = ctypes.c_void_p * len(part)
+        cols = [arr(*[ptr(it[k]) for it in part]) for k in range(4)]
+        check(L.load().fcd_instnorm_update_running_batch(cols[0], cols[1], cols[2], cols[3], len(part), n, c,
+                                                         int(groups), IN_MOMENTUM, stream()), "update_running_batch")
+
+
 def instnorm_apply(z, mean, rstd, gamma, beta, act_slope: float, residual=None, out=None):
     n, h, w, c = z.shape
     if out is None:

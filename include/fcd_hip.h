@@ -167,6 +167,14 @@ int fcd_instnorm_stats_from_running(const float* running_mean, const float* runn
 int fcd_instnorm_update_running(float* running_mean, float* running_var, const float* mean,
                                 const float* var_unbiased, int N, int C, int groups, float momentum,
                                 void* stream);
+/* The same update for up to FCD_RUNNING_BATCH_MAX tracked norms of one generator call in ONE launch (the
+ * reference makes them one by one inside nn.InstanceNorm2d.forward, models/fixed_point_gan.py:28,31; they
+ * are independent, so the order between norms is free).  The four arrays are HOST arrays of `count` device
+ * pointers; all norms share N, C, groups, momentum. */
+#define FCD_RUNNING_BATCH_MAX 16
+int fcd_instnorm_update_running_batch(float* const* running_mean, float* const* running_var,
+                                      const float* const* mean, const float* const* var_unbiased, int count,
+                                      int N, int C, int groups, float momentum, void* stream);
 /* y = act((z-mean)*rstd*gamma + beta) (+ residual); relu: act_slope 0, lrelu: 0.01, none: 1;
  * FCD_ACT_SILU / FCD_ACT_MISH in place of a slope select nn.SiLU / nn.Mish
  * (fixed_point_gan.py:13-16; instnorm_apply / instnorm_bwd only: the generator's activations). */
