@@ -65,6 +65,28 @@ def test_instnorm_running_stats_and_eval(dev):
     assert relerr(y.cpu(), nhwc(ref.detach())) <= 1e-5
 
 
+@pytest.mark.parametrize("groups", [1, 2])
+@pytest.mark.parametrize("count", [1, 12, 19])
+def test_running_update_batch_equals_single_updates(dev, count, groups):
+    """fcd_instnorm_update_running_batch (one launch for the tracked norms of a generator call; more than 16
+    norms go out in several launches) leaves the same bits as one fcd_instnorm_update_running per norm."""
+    from fcd_amd import ops
+    torch.manual_seed(5)
+    n, c = 32, 256
+    items, single = [], []
+    for _ in range(count):
+        rm, rv = torch.randn(c, device=dev), torch.rand(c, device=dev) + 0.5
+        mean, varu = torch.randn(n, c, device=dev), torch.rand(n, c, device=dev) + 0.1
+        items.append((rm.clone(), rv.clone(), mean, varu))
+        ops.instnorm_update_running(rm, rv, mean, varu, groups=groups)
+        single.append((rm, rv))
+    ops.instnorm_update_running_batch(items, groups=groups)
+    for (rm_b, rv_b, _, _), (rm_s, rv_s) in zip(items, single):
+        assert torch.equal(rm_b, rm_s) and torch.equal(rv_b, rv_s)
+    with pytest.raises(RuntimeError):
+        ops.instnorm_update_running_batch(items[:1] + [(items[0][0], items[0][1], items[0][2][:16], items[0][3][:16])])
+
+
 @pytest.mark.parametrize("rows,c", [(64, 2048), (65536, 64), (100, 12), (4096, 256)])
 def test_colsum(dev, rows, c):
     from fcd_amd import ops
