@@ -220,3 +220,44 @@ def test_diffmap_threshold_bit_exact(dev):
         diff, mask = ops.diffmap_threshold(xf0.to(dev), x0.to(dev), float(thr_s))
         assert torch.equal(diff.cpu().flatten(), vals)
         assert mask.cpu().flatten().tolist() == c["torch_gt"]
+
+
+def _split3_ref(v):
+    """fp32 -> three bf16 pieces, round to nearest even at each level (the layout of the *_x3 packs)."""
+    h = v.to(torch.bfloat16)
+    r = v - h.float()
+    m = r.to(torch.bfloat16)
+    l = (r - m.float()).to(torch.bfloat16)
+    return torch.stack([h, m, l])
+
+
+# (O, I, k, s, p): 4x4 shapes take the coalesced pack kernels (thread per (o, i) pair / 64 x 4 x 16 LDS tile),
+# the others (and O not a multiple of 64 for the adjoint) the element-per-thread ones
+@pytest.mark.parametrize("geom", [(128, 64, 4, 2, 1), (192, 8, 4, 2, 1), (40, 12, 4, 2, 1), (64, 10, 4, 2, 1),
+                                  (256, 32, 3, 1, 1), (10, 64, 7, 1, 3)])
+def test_weight_packs_match_the_documented_layout(dev, geom):
+    """fwd: [o][kh][kw][i]; adj: [phase][i][th][tw][o] with the taps of include/fcd_hip.h (stride 1: flipped;
+    4x4 stride 2: kh = 3 - py - 2 th); *_x3: the same elements as three bf16 planes.  Bit-exact."""
+    from fcd_amd import ops
+    O, I, k, s, p = geom
+    g = ops.ConvGeom(O, I, k, s, p)
+    torch.manual_seed(9)
+    w = torch.randn(O, I, k, k)
+    fwd = torch.zeros(O, k, k, g.IP)
+    fwd[..., :I] = w.permute(0, 2, 3, 1)
+    if s == 1:
+        adj = torch.zeros(1, I, k, k, g.OP)
+        adj[0, ..., :O] = w.flip(2, 3).permute(1, 2, 3, 0)
+    else:
+        adj = torch.zeros(4, I, 2, 2, g.OP)
+        for ph in range(4):
+            py, px = ph >> 1, ph & 1
+            for th in range(2):
+                for tw in range(2):
+                    adj[ph, :, th, tw, :O] = w[:, :, 3 - py - 2 * th, 3 - px - 2 * tw].t()
+    wd = w.to(dev)
+    assert torch.equal(ops.pack_weight_fwd(wd, g).cpu(), fwd)
+    assert torch.equal(ops.pack_weight_adj(wd, g).cpu(), adj)
+    assert torch.equal(ops.pack_weight_fwd_x3(wd, g).cpu().view(torch.int16), _split3_ref(fwd).view(torch.int16))
+    ax3 = ops.pack_weight_adj_x3(wd, g).cpu()                      # [phase][plane][i][th][tw][o]
+    assert torch.equal(ax3.view(torch.int16), _split3_ref(adj).transpose(0, 1).contiguous().view(torch.int16))
