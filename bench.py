@@ -136,6 +136,7 @@ def dominant_kernel_roofline(precision, dev, in_step_us=None, in_step_launches=0
             else "back-to-back loop", "us_per_launch_back_to_back_loop": round(loop_us, 2),
             "gflop_per_launch": round(flops / 1e9, 3),
             "engine_clock_mhz_under_kernel": sclk, "engine_clock_mhz_nominal": 2400,
+            "frac_at_measured_clock": round(achieved / peak * 2400.0 / sclk, 4) if sclk else None,
             "clock_note": "sysfs pp_dpm_sclk while this kernel runs back to back; the peaks above assume 2400 MHz, "
                           "so frac at the clock the card actually holds is frac * 2400 / engine_clock_mhz_under_kernel",
             "traffic": traffic,
