@@ -1211,7 +1211,6 @@ __global__ __launch_bounds__(64 * H7_WAVES) void conv7_halo_kernel(const GatherA
       wreg[t * 4 + c] = c16 < p.Cout
           ? *reinterpret_cast<const float4*>(p.w + (long)c16 * p.K + (wave * 7 + t) * 64 + 16 * c + 4 * g4)
           : make_float4(0.f, 0.f, 0.f, 0.f);
-  const float bs = (p.bias && c16 < p.Cout) ? p.bias[c16] : 0.f;
   wait_vmcnt<0>();
   __syncthreads();
 
@@ -1258,7 +1257,6 @@ __global__ __launch_bounds__(64 * H7_WAVES) void conv7_halo_kernel(const GatherA
       p.out[(((long)n * p.OH + y) * p.OW + x0 + px) * p.CoutP + co] = v;
     }
   }
-  (void)bs;
 }
 
 __global__ __launch_bounds__(256) void pack_fwd_kernel(const float* __restrict__ w, float* __restrict__ out,
