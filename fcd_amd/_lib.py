@@ -73,6 +73,7 @@ PROTOTYPES = {
     "fcd_head_wgrad": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "fcd_instnorm_workspace_bytes": (_Z, [_I, _I, _I]),
     "fcd_instnorm_stats": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _P, _Z, _P]),
+    "fcd_instnorm_stats_noalloc": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _P]),
     "fcd_instnorm_stats_from_running": (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),
     "fcd_instnorm_update_running": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _P]),
     "fcd_instnorm_update_running_batch": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),

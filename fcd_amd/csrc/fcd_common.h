@@ -16,6 +16,10 @@ void fcd_set_error(const char* fmt, ...);
 int fcd_finalize_stats(const double* partial, float* mean, float* rstd, float* var_unbiased, int N, long HW, int C,
                        int chunks, float eps, hipStream_t st);
 
+// norm.hip: resolves the current device's copy of the built-in scratch array of
+// fcd_instnorm_stats_noalloc (hipGetSymbolAddress, once per device; `device` must be current).
+int fcd_noalloc_scratch_init(int device);
+
 #define FCD_REQUIRE(cond, ...)            \
   do {                                    \
     if (!(cond)) {                        \

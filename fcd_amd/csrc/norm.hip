@@ -3,6 +3,7 @@
 // is touched with 16-byte accesses along the channel axis, partial sums are combined in
 // double precision in a fixed order (bitwise reproducible, no atomics).
 #include "fcd_common.h"
+#include <mutex>
 
 namespace {
 
@@ -335,6 +336,24 @@ extern "C" size_t fcd_instnorm_workspace_bytes(int N, int HW, int C) {
   return partial_bytes(N, HW, C) + (size_t)N * C * 2 * sizeof(float) + 64;
 }
 
+namespace {
+// Both statistics entry points: column partials into `partial`, then the finalize kernel.  Every
+// partial[n][chunk][c] entry the second kernel reads is written by the first, so the buffer needs no
+// clearing between calls.
+int stats_launch(const float* z, float* mean, float* rstd, float* var_unbiased, int N, int HW, int C, float eps,
+                 double* partial, hipStream_t st) {
+  ColPlan pl = col_plan(N, HW, C);
+  const size_t shm = (size_t)pl.rows * pl.c4b * 4 * 2 * sizeof(double);
+  hipLaunchKernelGGL((col_partial_kernel<MODE_STATS>), dim3(pl.chunks, N, pl.cblocks), dim3(256), shm, st, z, nullptr, nullptr,
+                     nullptr, nullptr, partial, (long)HW, C, pl, 0.f);
+  int rc = fcd_check_launch("instnorm_stats/partial");
+  if (rc) return rc;
+  hipLaunchKernelGGL((finalize_kernel<FIN_STATS>), dim3(fcd_cdiv(C, 32), N), dim3(256), 0, st, (const double*)partial, mean,
+                     rstd, var_unbiased, (long)HW, C, pl.chunks, eps, 0);
+  return fcd_check_launch("instnorm_stats/finalize");
+}
+}  // namespace
+
 extern "C" int fcd_instnorm_stats(const float* z, float* mean, float* rstd, float* var_unbiased, int N, int HW,
                                   int C, float eps, void* workspace, size_t workspace_bytes, void* stream) {
   int rc = check_nhwc("instnorm_stats", N, HW, C);
@@ -344,16 +363,71 @@ extern "C" int fcd_instnorm_stats(const float* z, float* mean, float* rstd, floa
     fcd_set_error("instnorm_stats: workspace too small");
     return FCD_EWORKSPACE;
   }
-  ColPlan pl = col_plan(N, HW, C);
-  hipStream_t st = fcd_stream(stream);
-  const size_t shm = (size_t)pl.rows * pl.c4b * 4 * 2 * sizeof(double);
-  hipLaunchKernelGGL((col_partial_kernel<MODE_STATS>), dim3(pl.chunks, N, pl.cblocks), dim3(256), shm, st, z, nullptr, nullptr,
-                     nullptr, nullptr, (double*)workspace, (long)HW, C, pl, 0.f);
-  rc = fcd_check_launch("instnorm_stats/partial");
+  return stats_launch(z, mean, rstd, var_unbiased, N, HW, C, eps, (double*)workspace, fcd_stream(stream));
+}
+
+// ------------------------------------------------------------------------------------------------
+// fcd_instnorm_stats_noalloc: the same two kernels with the column partials in a file-scope device
+// array instead of a caller-provided workspace, for callers that cannot allocate (HIP graph capture,
+// serving loops).  `scratch` is a host-side stand-in for the symbol, not a device address: host code
+// uses the per-device address hipGetSymbolAddress returned (each GPU holds its own copy).
+// ------------------------------------------------------------------------------------------------
+static __device__ __align__(256) unsigned char scratch[FCD_NOALLOC_SCRATCH_BYTES];
+
+namespace {
+constexpr int MAX_DEVICES = 64;
+std::mutex g_scratch_mu;
+void* g_scratch_ptr[MAX_DEVICES] = {};
+}  // namespace
+
+// With `device` current: resolve this device's copy of `scratch` once.  Called by fcd_init, and by the
+// entry point's first call on a device that fcd_init was not called for.
+int fcd_noalloc_scratch_init(int device) {
+  if (device < 0 || device >= MAX_DEVICES) {
+    fcd_set_error("noalloc scratch: device %d out of range", device);
+    return FCD_EINVAL;
+  }
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  if (g_scratch_ptr[device]) return FCD_OK;
+  void* p = nullptr;
+  hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+  if (e != hipSuccess || !p) {
+    fcd_set_error("noalloc scratch: hipGetSymbolAddress failed on device %d (%s)", device, hipGetErrorString(e));
+    return e != hipSuccess ? (int)e : FCD_ENODEVICE;
+  }
+  g_scratch_ptr[device] = p;
+  return FCD_OK;
+}
+
+extern "C" int fcd_instnorm_stats_noalloc(const float* z, float* mean, float* rstd, float* var_unbiased, int N, int HW,
+                                          int C, float eps, void* stream) {
+  int rc = check_nhwc("instnorm_stats_noalloc", N, HW, C);
   if (rc) return rc;
-  hipLaunchKernelGGL((finalize_kernel<FIN_STATS>), dim3(fcd_cdiv(C, 32), N), dim3(256), 0, st,
-                     (const double*)workspace, mean, rstd, var_unbiased, (long)HW, C, pl.chunks, eps, 0);
-  return fcd_check_launch("instnorm_stats/finalize");
+  FCD_REQUIRE(z && mean && rstd, "instnorm_stats_noalloc: null tensor");
+  const size_t need = partial_bytes(N, HW, C);
+  if (need > (size_t)FCD_NOALLOC_SCRATCH_BYTES) {
+    fcd_set_error("instnorm_stats_noalloc: N=%d HW=%d C=%d needs %zu bytes of column partials, the built-in scratch "
+                  "holds %zu; use fcd_instnorm_stats with a workspace", N, HW, C, need, (size_t)FCD_NOALLOC_SCRATCH_BYTES);
+    return FCD_EWORKSPACE;
+  }
+  int device = -1;
+  hipError_t e = hipGetDevice(&device);
+  if (e != hipSuccess || device < 0 || device >= MAX_DEVICES) {
+    fcd_set_error("instnorm_stats_noalloc: no current device (%s)", hipGetErrorString(e));
+    return FCD_ENODEVICE;
+  }
+  void* p;
+  {
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    p = g_scratch_ptr[device];
+  }
+  if (!p) {
+    rc = fcd_noalloc_scratch_init(device);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    p = g_scratch_ptr[device];
+  }
+  return stats_launch(z, mean, rstd, var_unbiased, N, HW, C, eps, (double*)p, fcd_stream(stream));
 }
 
 extern "C" int fcd_instnorm_stats_from_running(const float* running_mean, const float* running_var, float* mean,

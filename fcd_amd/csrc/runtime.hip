@@ -40,5 +40,5 @@ extern "C" int fcd_init(int device) {
     fcd_set_error("fcd_init: %s", hipGetErrorString(e));
     return (int)e;
   }
-  return FCD_OK;
+  return fcd_noalloc_scratch_init(device);
 }

@@ -158,6 +158,18 @@ int fcd_head_wgrad(const float* gout, const float* in, float* dw, int accumulate
 size_t fcd_instnorm_workspace_bytes(int N, int HW, int C);
 int fcd_instnorm_stats(const float* z, float* mean, float* rstd, float* var_unbiased, int N, int HW,
                        int C, float eps, void* workspace, size_t workspace_bytes, void* stream);
+/* fcd_instnorm_stats for callers that cannot allocate (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Same kernels and
+ * the same bits as fcd_instnorm_stats, but the column partials live in a device array built into the
+ * library (FCD_NOALLOC_SCRATCH_BYTES per GPU, held until the process ends; its address is resolved
+ * once per device, in fcd_init or on the first call) instead of a caller workspace: the call makes no
+ * hipMalloc / hipFree and takes no workspace.  Shapes whose partials exceed the array are rejected with
+ * FCD_EWORKSPACE (all InstanceNorm shapes of the baseline step fit: <= 4 MiB).  Every call on a GPU
+ * shares that GPU's array: calls that overlap on one GPU (two streams, two threads) race; calls on one
+ * stream are ordered.  Nothing has to be cleared between calls (every partial read is written first). */
+#define FCD_NOALLOC_SCRATCH_BYTES (4u << 20)
+int fcd_instnorm_stats_noalloc(const float* z, float* mean, float* rstd, float* var_unbiased, int N, int HW,
+                               int C, float eps, void* stream);
 /* eval mode of a tracked norm: mean/rstd broadcast from the running buffers. */
 int fcd_instnorm_stats_from_running(const float* running_mean, const float* running_var,
                                     float* mean, float* rstd, int N, int C, float eps, void* stream);
