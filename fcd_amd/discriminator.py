@@ -29,9 +29,11 @@ from .generator import ConvParams, _act_slope
 from .ops import ConvGeom
 
 class _State:
-    """Process-wide on purpose, not thread-local: autograd runs a CUDA graph's backward nodes on
-    its own worker thread, which must see the flag the calling thread set around
-    ``torch.autograd.grad`` (the call blocks until that backward is done)."""
+    """Fallback switch for ``input_grad_only()`` called without modules.  Process-wide on purpose, not
+    thread-local: autograd runs a CUDA graph's backward nodes on its own worker thread, which must see
+    the flag the calling thread set around ``torch.autograd.grad`` (the call blocks until that
+    backward is done).  Prefer ``input_grad_only(D)``: the flag then lives on the module, and two
+    solvers in one process do not share it."""
     input_only = False
 
 
@@ -39,15 +41,23 @@ _state = _State()
 
 
 @contextlib.contextmanager
-def input_grad_only():
-    """Inside this context D's backward skips parameter gradients (the GP's
-    ``autograd.grad(y, x, create_graph=True)`` only asks for d y / d x)."""
-    prev = getattr(_state, "input_only", False)
-    _state.input_only = True
+def input_grad_only(*modules):
+    """Inside this context the backward of the given Discriminators (all Discriminators of the
+    process when none is given) skips parameter gradients: the GP's
+    ``autograd.grad(y, x, create_graph=True)`` only asks for d y / d x."""
+    targets = modules if modules else (_state,)
+    prev = [getattr(t, "input_only", False) for t in targets]
+    for t in targets:
+        t.input_only = True
     try:
         yield
     finally:
-        _state.input_only = prev
+        for t, pv in zip(targets, prev):
+            t.input_only = pv
+
+
+def _input_only(mod) -> bool:
+    return bool(getattr(mod, "input_only", False) or _state.input_only)
 
 
 class _ConvAct(nn.Sequential):
@@ -106,6 +116,8 @@ class Discriminator(nn.Module):
         self._n_feat = min(n_feature_layers, len(layers))
         self._g1 = ConvGeom(1, cin, 3, 1, 1)
         self._g2 = ConvGeom(c_dim, cin, ks, 1, 0)
+        self._grad_hook = None        # parallel.BucketedReducer while a data-parallel D step runs
+        self.input_only = False       # input_grad_only(self): backward skips parameter gradients
 
     def _flat_params(self):
         out = []
@@ -150,7 +162,7 @@ class _DiscriminatorFn(torch.autograd.Function):
     def backward(ctx, g_src, g_cls, g_feat):
         mod = ctx.mod
         needs = ctx.needs_input_grad
-        want_params = any(needs[2:]) and not getattr(_state, "input_only", False)
+        want_params = any(needs[2:]) and not _input_only(mod)
         outs = _DBackwardFn.apply(mod, ctx.acts, ctx.prec, needs[1], want_params, g_src, g_cls, g_feat,
                                   *mod._flat_params())
         gx = outs[0]
@@ -178,6 +190,9 @@ class _DBackwardFn(torch.autograd.Function):
         # fcd_solver.py:361-385): start at the feature layer instead of pushing zeros through the
         # layers above it.
         only_feat = g_src is None and g_cls is None and g_feat is not None and not want_params
+        # data parallel: see _GeneratorFn.backward (parameters become final heads first, then layers downwards)
+        hook = mod._grad_hook
+        final = hook is not None and want_params and hook.pass_begin()
         # heads -> masked gradient at the top activation
         gz = None if only_feat else torch.empty_like(top)
         first = True
@@ -199,6 +214,9 @@ class _DBackwardFn(torch.autograd.Function):
                 grads[2 * nl + 1] = None if sink is not None else dw
         if first and gz is not None:
             gz.zero_()
+        if final:
+            hook.param_ready(mod.conv2.weight)
+            hook.param_ready(mod.conv1.weight)
         gzs = [None] * nl          # gzs[l] = masked gradient at layer l's pre-activation
         gx = None
         for li in range(mod._n_feat - 1 if only_feat else nl - 1, -1, -1):
@@ -221,6 +239,9 @@ class _DBackwardFn(torch.autograd.Function):
                 bs = ops.colsum(gz.numel() // gz.shape[3], gz, gz.shape[3], out=bsink, accumulate=bsink is not None)
                 if bsink is None:
                     grads[2 * li + 1] = bs if gz.shape[3] == g.O else bs[: g.O].contiguous()
+                if final:
+                    hook.param_ready(cv.bias)
+                    hook.param_ready(cv.weight)
             if li == 0:
                 if want_x:
                     d = g.adj_desc(n, gz.shape[1], gz.shape[2], precision=prec)
@@ -250,6 +271,10 @@ class _DBackwardFn(torch.autograd.Function):
         if gg_x is None:
             return (None,) * 8 + tuple(out)
         n = acts[0].shape[0]
+        # data parallel: this pass walks D upwards; when it is the step's last one (autograd usually runs it
+        # first) the spans simply complete in forward order
+        hook = mod._grad_hook
+        final = hook is not None and any(needs) and hook.pass_begin()
         u = ops.nchw_to_nhwc(gg_x.contiguous(), mod._geoms[0].IP)
         for li in range(nl):
             g = mod._geoms[li]
@@ -262,6 +287,9 @@ class _DBackwardFn(torch.autograd.Function):
                 out[2 * li] = None if sink is not None else dw
             if needs[2 * li + 1] and grad_sink(mod._convs[li].bias, True) is None:
                 out[2 * li + 1] = torch.zeros_like(mod._convs[li].bias)
+            if final:
+                hook.param_ready(mod._convs[li].weight)
+                hook.param_ready(mod._convs[li].bias)
             d = g.fwd_desc(n, u.shape[1], u.shape[2], precision=prec, mask_slope=mod._slopes[li])
             u = ops.conv_gather(d, u, mod._convs[li].operand("fwd", g, d), mask=acts[li + 1])
         if needs[2 * nl] and ctx.g_src is not None:
@@ -273,6 +301,9 @@ class _DBackwardFn(torch.autograd.Function):
             dw = ops.head_wgrad(ctx.g_cls.contiguous().view(n, mod.c_dim, 1, 1), u, mod._g2.I, mod._g2.k, 0, dw=sink,
                                 accumulate=sink is not None)
             out[2 * nl + 1] = None if sink is not None else dw
+        if final:
+            hook.param_ready(mod.conv1.weight)
+            hook.param_ready(mod.conv2.weight)
         # d/d g_src, d/d g_cls (linear) are not needed by the GP: grad_outputs is a constant
         ctx.gzs = None
         return (None,) * 8 + tuple(out)
@@ -320,7 +351,7 @@ class _SmoothDiscriminatorFn(torch.autograd.Function):
     def backward(ctx, g_src, g_cls, g_feat):
         mod = ctx.mod
         needs = ctx.needs_input_grad
-        want_params = any(needs[2:]) and not getattr(_state, "input_only", False)
+        want_params = any(needs[2:]) and not _input_only(mod)
         outs = _SmoothDBackwardFn.apply(mod, ctx.acts, ctx.zs, ctx.prec, needs[1], want_params, g_src, g_cls, g_feat,
                                         *mod._flat_params())
         res = [None, outs[0] if needs[1] else None]
@@ -342,6 +373,8 @@ class _SmoothDBackwardFn(torch.autograd.Function):
         top = acts[-1]
         nl = len(mod._convs)
         grads: List[Optional[torch.Tensor]] = [None] * (2 * nl + 2)
+        if mod._grad_hook is not None and want_params:
+            mod._grad_hook.pass_begin()       # counted; spans of the SiLU / Mish path go out after backward
         ga = torch.empty_like(top)            # cotangent of a_top (no activation factor yet)
         first = True
         if g_src is not None:
@@ -409,6 +442,8 @@ class _SmoothDBackwardFn(torch.autograd.Function):
         if gg_x is None:
             return (None,) * 9 + tuple(out)
         n = acts[0].shape[0]
+        if mod._grad_hook is not None and any(needs):
+            mod._grad_hook.pass_begin()
 
         def add_w(li, gz, a):
             sink = grad_sink(mod._convs[li].weight, True)

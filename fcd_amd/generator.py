@@ -79,16 +79,17 @@ class ConvParams(nn.Module):
         return t
 
 
-    def folded(self, geom: ConvGeom, d, norm) -> tuple:
+    def folded(self, geom: ConvGeom, d, norm, epoch: int = 0) -> tuple:
         """Inference only: the forward operand with a tracked InstanceNorm's eval-mode transform folded
         in.  With running statistics the norm is the per-channel affine map ``z * s + t``,
         ``s = gamma / sqrt(running_var + eps)``, ``t = beta - running_mean * s`` (what
         ``nn.InstanceNorm2d(track_running_stats=True)`` computes in eval mode, fixed_point_gan.py:28,31), so ``norm(conv(a, W)) == conv(a, W * s) + t``: the scaled weights
-        are packed once per set of parameter / buffer versions, ``t`` goes in as the bias, the activation
+        are packed once per set of parameter / buffer versions (``epoch``: the generator's count of
+        kernel-side running-statistics updates, which bypass tensor versions), ``t`` goes in as the bias, the activation
         and the residual add ride in the convolution's epilogue, and no norm kernel runs at all."""
         srcs = (self.weight, norm.weight, norm.bias, norm.running_mean, norm.running_var)
         x3 = ops.wants_split_weights(d)
-        key = tuple((t.data_ptr(), t._version) for t in srcs) + (x3, str(self.weight.device))
+        key = tuple((t.data_ptr(), t._version) for t in srcs) + (x3, str(self.weight.device), epoch)
         hit = self._packed.get("folded")
         if hit is not None and hit[0] == key:
             return hit[1]
@@ -188,6 +189,9 @@ class Generator(nn.Module):
         self.main = nn.Sequential(*mods)
         self._plan = plan
         self._groups = 1
+        self._grad_hook = None        # parallel.BucketedReducer while a data-parallel G step runs
+        self._grad_mode = True        # torch.is_grad_enabled() at the last forward call
+        self._stats_epoch = 0         # bumped whenever a kernel rewrites the running statistics
 
     @contextlib.contextmanager
     def sample_groups(self, groups: int):
@@ -217,6 +221,7 @@ class Generator(nn.Module):
             raise RuntimeError("fcd_amd.Generator runs on the MI355X HIP path only; move inputs and module to cuda")
         x = x.contiguous().float()
         c = c.contiguous().float().view(x.size(0), -1)
+        self._grad_mode = torch.is_grad_enabled()     # (always False inside Function.forward)
         return _GeneratorFn.apply(self, x, c, *self._flat_params())
 
 
@@ -232,7 +237,9 @@ class _GeneratorFn(torch.autograd.Function):
         plan = mod._plan
         if n % mod._groups:
             raise RuntimeError(f"Generator: batch {n} is not a multiple of sample_groups({mod._groups})")
-        inference = not any(ctx.needs_input_grad)       # no backward will ask for the per-layer tensors
+        # no backward will ask for the per-layer tensors: torch.no_grad(), or nothing requires grad
+        # (needs_input_grad follows the inputs' requires_grad flags, not the grad mode)
+        inference = not mod._grad_mode or not any(ctx.needs_input_grad)
         cp = plan[0].geom.IP
         acts = [ops.g_prologue(x, c, cp)]      # acts[i] = input of layer i
         saved = []                              # per layer: (z, mean, rstd, use_running)
@@ -249,7 +256,7 @@ class _GeneratorFn(torch.autograd.Function):
             if use_running and inference and ly.kind == "conv" and ly.act_slope <= 1.0:
                 # eval-mode norm folded into the convolution (nothing is kept for a backward pass)
                 d = g.fwd_desc(n, a.shape[1], a.shape[2], precision=prec, act_slope=ly.act_slope)
-                wp, shift = ly.conv.folded(g, d, nm)
+                wp, shift = ly.conv.folded(g, d, nm, mod._stats_epoch)
                 res = acts[li + 1 + ly.res_from] if ly.res_from is not None else None
                 acts.append(ops.conv_gather(d, a, wp, bias=shift, residual=res))
                 saved.append(None)
@@ -283,6 +290,8 @@ class _GeneratorFn(torch.autograd.Function):
             acts.append(y)
         for items in running.values():
             ops.instnorm_update_running_batch(items, groups=mod._groups)
+        if running:
+            mod._stats_epoch += 1      # raw-pointer writes do not bump tensor versions: folded() keys on this
         x_fake = ops.g_epilogue_fwd(acts[-1], x)
         ctx.mod = mod
         ctx.acts = acts
@@ -306,6 +315,10 @@ class _GeneratorFn(torch.autograd.Function):
         # which params need grads (inputs: mod, x, c, *params)
         needs = ctx.needs_input_grad[3:]
         grads: List[Optional[torch.Tensor]] = [None] * len(needs)
+        # data parallel: in the step's last pass through G every parameter gradient is final as soon as
+        # its kernel is enqueued, and its arena span can go to the all-reduce beside the rest of the chain
+        hook = mod._grad_hook
+        final = hook is not None and any(needs) and hook.pass_begin()
         # index of each layer's first param
         pidx = []
         k = 0
@@ -337,6 +350,9 @@ class _GeneratorFn(torch.autograd.Function):
                         grads[p0 + 1] = dgam
                     if needs[p0 + 2]:
                         grads[p0 + 2] = dbet
+                if final:
+                    hook.param_ready(ly.norm.bias)
+                    hook.param_ready(ly.norm.weight)
             else:
                 dz = g
             # weight gradient
@@ -350,6 +366,8 @@ class _GeneratorFn(torch.autograd.Function):
                     dw = ops.conv_wgrad(wd, a_in, dz, dw=sink)
                 if sink is None:
                     grads[p0] = dw
+            if final:
+                hook.param_ready(ly.conv.weight)
             # data gradient
             if li == 0:
                 if need_x:

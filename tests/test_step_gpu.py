@@ -215,7 +215,9 @@ def test_arena_gradients_match_fixtures(dev, tiny):
     b = batch_of(z, dev)
     s.alpha_override = torch.from_numpy(z["alpha"])
     s.G.requires_grad_(False)
-    s.training_step(b, 0, 0).backward()
+    loss = s.training_step(b, 0, 0)
+    with s.arenas[0].accumulating():
+        loss.backward()
     for name, p in s.D.named_parameters():
         assert relerr(p.grad, torch.from_numpy(z["dgrad." + name])) <= TOL, name
     s.G.requires_grad_(True)
@@ -224,7 +226,9 @@ def test_arena_gradients_match_fixtures(dev, tiny):
     s2.optimizers()
     s2.D.requires_grad_(False)
     s2.global_step = s2.n_critic - 1
-    s2.training_step(b, 0, 1).backward()
+    loss = s2.training_step(b, 0, 1)
+    with s2.arenas[1].accumulating():
+        loss.backward()
     for name, p in s2.G.named_parameters():
         assert relerr(p.grad, torch.from_numpy(z["ggrad." + name])) <= TOL, name
 
@@ -341,6 +345,14 @@ def build_variant(name, cfg, dev):
     return s.to(dev)
 
 
+def _backward(s, loss, optimizer_idx, arena):
+    if arena:
+        with s.arenas[optimizer_idx].accumulating():     # kernels add into p.grad (the arena) themselves
+            loss.backward()
+    else:
+        loss.backward()
+
+
 @pytest.mark.parametrize("name", list(VARIANTS))
 @pytest.mark.parametrize("prec", ["fp32", "fp32x3", "fp32-arena"])
 def test_variant_steps(dev, tiny, name, prec):
@@ -365,7 +377,7 @@ def test_variant_steps(dev, tiny, name, prec):
     # D step
     s.alpha_override = alpha
     s.G.requires_grad_(False)
-    s.training_step(b, 0, 0).backward()
+    _backward(s, s.training_step(b, 0, 0), 0, arena)
     for k in [k for k in v.files if k.startswith(f"{name}.dloss.")]:
         ref = float(v[k])
         assert abs(float(s.loss_dict[k.split(".dloss.")[1]]) - ref) <= TOL * max(1.0, abs(ref)), k
@@ -381,7 +393,7 @@ def test_variant_steps(dev, tiny, name, prec):
     s.set_precision(prec)
     s.D.requires_grad_(False)
     s.global_step = s.n_critic - 1
-    s.training_step(b, 0, 1).backward()
+    _backward(s, s.training_step(b, 0, 1), 1, arena)
     gl = [k for k in v.files if k.startswith(f"{name}.gloss.")]
     assert len(gl) == (10 if VARIANTS[name][4] else 7)
     for k in gl:
@@ -548,3 +560,114 @@ def test_all_nodata_sample_and_constant_channels(dev):
         assert abs(float(s.loss_dict[k]) - float(v)) <= TOL * max(1.0, abs(float(v))), k
     for pname, p in s.G.named_parameters():
         assert torch.isfinite(p.grad).all() and relerr(p.grad, gg[pname]) <= TOL, pname
+
+
+# --------------------------------------------------------------------------- #
+# eval-mode folding, arena safety (round-1 advisor findings)
+# --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("prec", ["fp32", "fp32x3"])
+def test_folded_eval_equals_unfolded_eval(dev, tiny, prec):
+    """Under torch.no_grad() the eval-mode generator folds the tracked InstanceNorms into the
+    convolutions (ConvParams.folded); with grad enabled and parameters requiring grad it takes the
+    unfolded stats_from_running + in_apply path.  Same outputs and masks, and a fold must not survive
+    a kernel-side change of the running statistics (a train-mode forward between two evals)."""
+    z, sc = tiny
+    s = build(z, sc["cfg"], dev)
+    s.set_precision(prec)
+    b = batch_of(z, dev)
+    c0 = torch.zeros_like(b[2])
+
+    def both():
+        s.G.eval()
+        with torch.no_grad():
+            folded = s.G(b[0], c0)
+        assert any("folded" in m._packed for m in s.G.modules() if hasattr(m, "_packed"))
+        with torch.enable_grad():
+            unfolded = s.G(b[0], c0).detach()
+        return folded, unfolded
+
+    f1, u1 = both()
+    assert relerr(f1, u1) <= 1e-5
+    assert relerr(f1, torch.from_numpy(z["G_eval_out"])) <= TOL
+    d_f, m_f = ops_diff(f1, b[0], sc["thr"])
+    d_u, m_u = ops_diff(u1, b[0], sc["thr"])
+    far = (d_u - sc["thr"]).abs() > 1e-5
+    assert bool((m_f[far] == m_u[far]).all())
+    # running statistics move (weights unchanged: a D-only phase), then eval again
+    s.G.train()
+    with torch.no_grad():
+        for _ in range(3):
+            s.G(b[0] * 0.5, b[2])
+    f2, u2 = both()
+    assert relerr(f2, u2) <= 1e-5                      # a stale fold would reproduce f1 instead
+    assert relerr(f2, f1) > 1e-4
+    # and torch-side writes (load_state_dict) invalidate it as well
+    s.G.load_state_dict({k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("G.")})
+    f3, u3 = both()
+    assert relerr(f3, f1) <= 1e-6 and relerr(f3, u3) <= 1e-5
+
+
+def ops_diff(x_fake, x, thr):
+    from fcd_amd import ops
+    return ops.diffmap_threshold(x_fake.contiguous(), x.contiguous(), float(thr))
+
+
+def test_arena_untouched_by_autograd_grad(dev, tiny):
+    """A reference-style gradient_penalty (no input_grad_only) on arena-backed parameters:
+    torch.autograd.grad(..., create_graph=True) must leave p.grad alone; only a backward inside
+    arena.accumulating() writes the arena directly."""
+    z, sc = tiny
+    s = build(z, sc["cfg"], dev)
+    s.optimizers()
+    ar = s.arenas[0]
+    assert ar.intact() and not ar.direct
+    def penalty():
+        x = batch_of(z, dev)[0].clone().requires_grad_(True)
+        src, _, _ = s.D(x)
+        dydx = torch.autograd.grad(outputs=src, inputs=x, grad_outputs=torch.ones_like(src), retain_graph=True,
+                                   create_graph=True, only_inputs=True)[0]
+        torch.cuda.synchronize()
+        assert float(ar.grad.abs().sum()) == 0.0          # the first-order pass left the arena alone
+        return torch.mean((torch.sqrt(torch.sum(dydx.view(dydx.size(0), -1) ** 2, dim=1)) - 1) ** 2)
+
+    # outside accumulating(): gradients travel through autograd into p.grad (the arena views)
+    penalty().backward()
+    via_autograd = ar.grad.clone()
+    assert float(via_autograd.abs().sum()) > 0 and ar.intact()
+    ar.zero_grad()
+    gp = penalty()
+    with ar.accumulating():
+        gp.backward()
+    assert relerr(ar.grad, via_autograd) <= 1e-6 and not ar.direct
+
+
+def test_adam_arena_state_dict_round_trip(dev, tiny):
+    """FusedAdam with an arena: state saved after two steps and loaded into a fresh optimizer
+    continues with the same bits (the flat moment buffers are seeded from the loaded state)."""
+    z, sc = tiny
+    b = batch_of(z, dev)
+
+    def fresh():
+        s = build(z, sc["cfg"], dev)
+        s.alpha_override = torch.from_numpy(z["alpha"])
+        return s
+
+    a = fresh()
+    for _ in range(2):
+        a.train_step(b, force_g=True)
+    a._flush_pending()
+    import copy
+    saved = copy.deepcopy({"G": a.G.state_dict(), "D": a.D.state_dict(),       # state_dict() aliases live storage
+                           "opt": [o.state_dict() for o in a.optimizers()]})
+    a.train_step(b, force_g=True)
+    c = fresh()
+    c.G.load_state_dict(saved["G"])
+    c.D.load_state_dict(saved["D"])
+    for o, sd in zip(c.optimizers(), saved["opt"]):
+        o.load_state_dict(sd)
+    c.global_step = 2
+    c.train_step(b, force_g=True)
+    torch.cuda.synchronize()
+    for net_a, net_c in ((a.G, c.G), (a.D, c.D)):
+        for (k, va), vc in zip(net_a.state_dict().items(), net_c.state_dict().values()):
+            assert torch.equal(va, vc), k
