@@ -189,6 +189,32 @@ def inference_rate(solver, dev, iters=5):
             "value": round(64 * iters / dt, 1), "unit": "images/sec", "ms_per_batch": round(dt / iters * 1e3, 2)}
 
 
+def inference_scene_rate(solver, dev, iters=3):
+    """BASELINE.json configs[3] at its stated size: the mask of a tiled synthetic Landsat-8 scene
+    (2000 x 1900 x 10 uint16, nodata border), 128x128 patches, batch 64, G in eval mode -- host array in,
+    host raster + mask out: upload, per-tile nodata flags (one copy), tiling + normalisation, G, difference
+    map, float64 stitch, nodata zeroing and float64 threshold on the device, download."""
+    from fcd_amd.scene import generate_scene_mask
+    from fcd_amd.synth import synth_scene
+    h, w = 2000, 1900
+    scene = synth_scene(h, w, BASE["bands"], seed=4, border=48)
+    was_training = solver.G.training
+    solver.G.eval()
+    generate_scene_mask(scene, solver, threshold=0.02, batch_size=64)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        _, mask = generate_scene_mask(scene, solver, threshold=0.02, batch_size=64)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    solver.G.train(was_training)
+    tiles = -(-h // BASE["size"]) * -(-w // BASE["size"])
+    return {"workload": f"generate_masks over a tiled synthetic scene {h}x{w}x{BASE['bands']} uint16, 128x128 patches, batch 64 "
+                        "(BASELINE.json configs[3]); host scene in, host float64 raster + uint8 mask out",
+            "ms_per_scene": round(dt * 1e3, 2), "tiles": tiles, "tiles_per_sec": round(tiles / dt, 1),
+            "mpixel_per_sec": round(h * w / dt / 1e6, 1), "mask_popcount": int(mask.sum())}
+
+
 def input_pipeline_rate(dev, iters=20):
     """Input pipeline: a training batch gathered from a uint16 patch pool
     resident in HBM (random indices, random flips): 20 B read + 40 B written per pixel."""
@@ -247,10 +273,21 @@ def cpu_baseline(timed_steps=3):
     for i in range(timed_steps):
         one_step(2 + i)
     dt = (time.perf_counter() - t0) / timed_steps
+    # inference leg (fcd_solver.py:802-807, 762): G eval + difference map + fp32 threshold on a batch of 64
+    xb, _ = O.synth_batch(64, BASE["size"], BASE["bands"], seed=7)
+    with torch.no_grad():
+        O.threshold_mask(O.difference_map(gs, xb[0][:8], False), 0.027)          # warm-up
+        t1 = time.perf_counter()
+        O.threshold_mask(O.difference_map(gs, xb[0], False), 0.027)
+        dti = time.perf_counter() - t1
     return {"value": round(BASE["batch"] / dt, 3), "unit": "images/sec", "cores": cores, "kind": "port",
             "sample": f"{timed_steps} full G+D steps (D-step+GP, G-step, Adam x2) after 1 warm-up step, B=16, "
                       "128x128x10, fp32, torch CPU kernels",
-            "seconds_per_step": round(dt, 2)}
+            "seconds_per_step": round(dt, 2),
+            "inference": {"value": round(64 / dti, 2), "unit": "images/sec", "cores": cores, "kind": "port",
+                          "sample": "one batch of 64: G eval forward + difference map + fp32 threshold "
+                                    "(oracle difference_map / threshold_mask), torch CPU kernels",
+                          "seconds_per_batch": round(dti, 2)}}
 
 
 def main():
@@ -266,7 +303,24 @@ def main():
     ap.add_argument("--backend", default=os.environ.get("FCD_DIST_BACKEND", "nccl"),
                     help="torch.distributed backend: nccl (= RCCL over xGMI); gloo only to rehearse the "
                          "multi-rank code path on a box with fewer GPUs than ranks")
+    ap.add_argument("--quick", action="store_true",
+                    help="only the timed steps and the headline fields (no roofline / inference / CPU legs)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` by hand: start N ranks (one per GPU) BEFORE this process touches a GPU,
+        # relay rank 0's JSON line and leave with the launcher's status.  (The driver starts the ranks itself
+        # with `python -m torch.distributed.run ... bench.py --gpus N`; then WORLD_SIZE is set and this is skipped.)
+        import socket
+        import subprocess
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        raise SystemExit(subprocess.call(cmd, env=env))
 
     if os.environ.get("FCD_HANG_DUMP"):           # debugging aid: stack of every thread after N seconds
         import faulthandler
@@ -274,6 +328,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); reporting n_gpus = {world}",
+              file=sys.stderr, flush=True)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the FCD hot path has no CPU fallback")
     ndev = torch.cuda.device_count()
@@ -330,10 +387,20 @@ def main():
             step()
         torch.cuda.synchronize()
         ops.KERNEL_TIMER = None
+    dist_info = {"world_size": 1, "backend": None}
     if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        early = [r[1].fired_early for _, r in sorted(solver._reducers.items())]
+        dist_info = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                     "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if args.backend == "nccl" else None,
+                     "grad_allreduce": "bucketed, issued from inside the last backward pass of each network "
+                                       f"(spans of {solver.bucket_mb[0]:g} MB for D, {solver.bucket_mb[1]:g} MB for G; D's update deferred "
+                                       "behind the generator forwards of the G step)",
+                     "spans_sent_from_inside_backward_last_step": {"D": early[0] if early else 0,
+                                                                   "G": early[1] if len(early) > 1 else 0},
+                     "ranks_per_visible_gpu": -(-world // max(1, ndev))}
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -348,8 +415,14 @@ def main():
                "config": {"workload": "FCD G+D train step incl. gradient penalty, batch 16/GPU, 128x128x10, "
                                       "6 res blocks, D x6 (BASELINE.json configs[1])",
                           "global_batch": BASE["batch"] * world, "parallelism": f"dp{world}",
-                          "precision": args.precision},
+                          "precision": args.precision, **dist_info},
                "step_tflops": round(GFLOP_PER_IMG * BASE["batch"] / (ms * 1e-3) / 1e3, 2)}
+        if args.quick:
+            print(json.dumps(res), flush=True)
+            if dist is not None:
+                dist.barrier()
+                dist.destroy_process_group()
+            return
         res["roofline"] = dominant_kernel_roofline(args.precision, dev,
                                                    timer.mean_us("dominant") if timer.pairs else None,
                                                    timer.count("dominant"), symbol=timer.total() if timer.pairs else None)
@@ -369,6 +442,7 @@ def main():
                                       "ms_per_step": round(dt1 / args.steps * 1e3, 3)}
         res["roofline_hbm"] = hbm_kernel_roofline(dev)
         res["inference"] = inference_rate(solver, dev)
+        res["inference_scene"] = inference_scene_rate(solver, dev)
         res["input_pipeline"] = input_pipeline_rate(dev)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()

@@ -14,8 +14,10 @@ Mirrors the pieces of the reference's ``data_loader.py`` that sit directly in fr
 * ``PatchLoader``       <- ``get_loader`` (``:398-428``): batch size doubled outside training,
   shuffling in training, HorizontalFlip / VerticalFlip with p = 0.5 each (``:372-373``).
   The reference's ``Affine(translate_percent=0.2)`` (``:374``) interpolates at sub-pixel shifts;
-  here the shift is rounded to whole pixels (``max_shift``; 0 = off, the default) -- the
-  augmentation draws are random on both sides, so nothing downstream depends on the difference.
+  here the shift is rounded to whole pixels (``max_shift``).  NOTE the default is 0 = no
+  translation, unlike the reference, whose training transform always shifts by up to 20 % (and
+  thereby feeds nodata pixels into G's invalid mask): pass ``max_shift=round(0.2 * H)`` to train
+  with the reference's augmentation strength.
 * ``on_before_batch_transfer`` <- ``L8BiomeDataModule.on_before_batch_transfer`` (``:56-71``).
 
 HDF5 itself is a storage format and out of scope; ``from_hdf5`` is a thin convenience that needs
@@ -104,11 +106,14 @@ class L8BiomePatchPool:
 
     def gather(self, positions: torch.Tensor, aug: Optional[torch.Tensor] = None, ret_mask: bool = False):
         """positions: int64 positions into the pool's (selected, possibly shuffled) index list."""
-        positions = positions.to(self.device, torch.int64)
         if positions.numel() == 0:
             raise ValueError("empty batch")
-        if int(positions.min()) < 0 or int(positions.max()) >= len(self):
-            raise IndexError("patch position outside the pool")
+        if not positions.is_cuda:
+            # range check on the host, before the upload: no device-to-host sync in the batch loop
+            if int(positions.min()) < 0 or int(positions.max()) >= len(self):
+                raise IndexError("patch position outside the pool")
+        positions = positions.to(self.device, torch.int64)
+        # (positions already on the device: torch's indexing kernel asserts the range itself)
         index = self.indices[positions].contiguous()
         if aug is not None:
             aug = aug.to(self.device, torch.int32).contiguous()
@@ -126,7 +131,7 @@ class PatchLoader:
 
     def __init__(self, pool: L8BiomePatchPool, batch_size: int = 16, mode: str = "train", shuffle: Optional[bool] = None,
                  force_no_aug: bool = False, ret_mask: bool = False, max_shift: int = 0,
-                 generator: Optional[torch.Generator] = None, rank: int = 0, world_size: int = 1):
+                 generator: Optional[torch.Generator] = None, rank: int = 0, world_size: int = 1, seed: int = 0):
         if mode != "train":
             batch_size *= 2                              # :404-405
         self.pool, self.batch_size, self.mode = pool, batch_size, mode
@@ -135,6 +140,7 @@ class PatchLoader:
         self.ret_mask, self.max_shift = ret_mask, int(max_shift)
         self.generator = generator
         self.rank, self.world_size = rank, world_size    # DistributedSampler-style striding
+        self.seed, self.epoch = int(seed), 0             # the shuffle every rank must agree on
 
     def __len__(self) -> int:
         n = (len(self.pool) + self.world_size - 1) // self.world_size
@@ -152,7 +158,15 @@ class PatchLoader:
 
     def __iter__(self) -> Iterator[Dict[str, torch.Tensor]]:
         n = len(self.pool)
-        order = torch.randperm(n, generator=self.generator) if self.shuffle else torch.arange(n)
+        if not self.shuffle:
+            order = torch.arange(n)
+        elif self.world_size > 1:
+            # every rank draws the SAME permutation (seed + epoch, as DistributedSampler.set_epoch does),
+            # so the rank-strided slices partition it; `generator` only drives the augmentation draws
+            order = torch.randperm(n, generator=torch.Generator().manual_seed(self.seed + self.epoch))
+        else:
+            order = torch.randperm(n, generator=self.generator)
+        self.epoch += 1
         if self.world_size > 1:
             pad = (-n) % self.world_size                # wrap around like DistributedSampler
             order = torch.cat([order, order[:pad]])[self.rank::self.world_size]

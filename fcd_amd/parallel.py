@@ -7,7 +7,7 @@ stream and unpacked before the optimizer reads them.  Works with the ``gloo`` ba
 CPU tensors too (the world_size-2 tests)."""
 from __future__ import annotations
 
-from typing import List, Sequence
+from typing import List, Optional, Sequence
 
 import torch
 import torch.distributed as dist
@@ -95,6 +95,45 @@ class GradSync:
     def allreduce_flat(self, flat: torch.Tensor) -> None:
         self.finish(self.allreduce_flat_async(flat))
 
+    def bucketed(self, arena, bucket_mb: Optional[float] = None) -> "BucketedReducer":
+        """An overlapped reducer for one gradient arena (see :class:`BucketedReducer`)."""
+        return BucketedReducer(self, arena, self.bucket_elems if bucket_mb is None else int(bucket_mb * (1 << 20) / 4))
+
+    def broadcast_buffers(self, modules, src: int = 0) -> None:
+        """Rank ``src``'s floating-point buffers (the Generator's tracked InstanceNorm running
+        statistics) to every rank, as ONE flat broadcast.  DDP's ``broadcast_buffers=True``
+        (Lightning's ``strategy='ddp'``, ``fcd_main.py:54-64``) re-broadcasts rank 0's buffers at
+        every forward; training-mode numerics never read them, so doing it once before they are
+        used (eval, validation, threshold search, checkpoint) gives every rank the statistics the
+        reference's ranks would hold: rank 0's chain of updates."""
+        if self.world == 1:
+            return
+        bufs = [b for m in modules for b in m.buffers() if b.is_floating_point() and b.numel()]
+        if not bufs:
+            return
+        flat = torch.cat([b.detach().reshape(-1).float() for b in bufs])
+        staged = dist.get_backend(self.group) != "nccl" and flat.is_cuda
+        t = flat.cpu() if staged else flat
+        dist.broadcast(t, src, group=self.group)
+        if staged:
+            flat = t.to(flat.device)
+        off = 0
+        with torch.no_grad():
+            for b in bufs:
+                b.copy_(flat[off:off + b.numel()].view_as(b))      # copy_ bumps the version: folded weights are rebuilt
+                off += b.numel()
+
+    def sum_counts(self, t: torch.Tensor) -> torch.Tensor:
+        """Integer counts (confusion matrices, histograms) summed over ranks, in place."""
+        if self.world == 1:
+            return t
+        staged = dist.get_backend(self.group) != "nccl" and t.is_cuda
+        h = t.cpu() if staged else t
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+        if staged:
+            t.copy_(h)
+        return t
+
     def broadcast_params(self, modules) -> None:
         """Identical initial weights and buffers on all ranks (DDP does this at construction)."""
         if self.world == 1:
@@ -108,3 +147,89 @@ class GradSync:
                     t.data.copy_(h)
                 else:
                     dist.broadcast(t.data, 0, group=self.group)
+
+
+class BucketedReducer:
+    """Gradient all-reduce overlapped with backward, for one :class:`fcd_amd.arena.ParamArena`.
+
+    The arena is cut into spans at parameter boundaries, walking from its END (parameters are laid
+    out in forward order, so backward finishes them last-to-first) and closing a span once it holds
+    ``bucket_elems`` elements.  A network's parameter gradients are final only in the LAST backward
+    pass of an optimizer step that touches them (the G step back-propagates through the generator 2
+    or 4 times, the D step through the discriminator 2 or 3 times), so the solver declares the number
+    of passes with :meth:`begin`; every hand-written backward chain calls :meth:`pass_begin`, and in
+    the final pass :meth:`param_ready` right after it has enqueued the kernel that completes a
+    parameter's gradient.  When the last parameter of a span is ready the span goes to the collective
+    (views of the arena itself, pieces of at most ``bucket_elems``), which RCCL orders after the work
+    already enqueued on the calling stream and runs on its own stream beside the rest of backward.
+    :meth:`finish_rest` sends whatever is left and returns the handle for ``GradSync.finish``.
+
+    Reporting more passes than declared means spans were reduced before their gradients were
+    complete: that raises.  Fewer passes (a backward path without hooks) only loses the overlap."""
+
+    def __init__(self, sync: GradSync, arena, bucket_elems: int):
+        self.sync, self.arena, self.bucket_elems = sync, arena, max(1, int(bucket_elems))
+        n = len(arena.params)
+        ends = list(arena.offsets[1:]) + [arena.flat.numel()]
+        self.spans = []                 # (lo, hi) element ranges, last span of the arena first
+        self.span_of = [0] * n          # parameter index -> span index
+        hi, size, members = ends[-1], 0, []
+        for i in range(n - 1, -1, -1):
+            members.append(i)
+            size += ends[i] - arena.offsets[i]
+            if size >= self.bucket_elems or i == 0:
+                for m in members:
+                    self.span_of[m] = len(self.spans)
+                self.spans.append((arena.offsets[i], hi))
+                hi, size, members = arena.offsets[i], 0, []
+        self.span_size = [0] * len(self.spans)
+        for i in range(n):
+            self.span_size[self.span_of[i]] += 1
+        self.declared = 0
+        self.begin(0)
+
+    def begin(self, passes: int) -> None:
+        self.declared, self.seen = int(passes), 0
+        self.missing = list(self.span_size)
+        self.ready = [False] * len(self.arena.params)
+        self.fired = [False] * len(self.spans)
+        self.handle = []
+        self.fired_early = 0
+        self.in_final = False
+
+    def pass_begin(self) -> bool:
+        """Called by a backward chain before its first parameter gradient; True in the final pass."""
+        self.seen += 1
+        if self.declared and self.seen > self.declared:
+            raise RuntimeError(f"BucketedReducer: backward pass {self.seen} after {self.declared} were declared: "
+                               "gradient spans may have been reduced before they were complete")
+        # early sends are only valid when the kernels write into the arena themselves
+        # (arena.accumulating()); gradients carried by autograd arrive after the chain has returned
+        self.in_final = self.declared > 0 and self.seen == self.declared and self.arena.direct
+        return self.in_final
+
+    def _fire(self, si: int) -> None:
+        lo, hi = self.spans[si]
+        self.fired[si] = True
+        for off in range(lo, hi, self.bucket_elems):
+            self.handle += self.sync.allreduce_flat_async(self.arena.grad[off:min(hi, off + self.bucket_elems)])
+
+    def param_ready(self, p) -> None:
+        i = self.arena.index.get(id(p))
+        if not self.in_final or i is None or self.ready[i]:
+            return
+        self.ready[i] = True
+        si = self.span_of[i]
+        self.missing[si] -= 1
+        if self.missing[si] == 0 and not self.fired[si]:
+            self._fire(si)
+            self.fired_early += 1
+
+    def finish_rest(self):
+        """After backward has returned: reduce the spans that were not sent from inside it."""
+        for si in range(len(self.spans)):
+            if not self.fired[si]:
+                self._fire(si)
+        h, self.handle = self.handle, []
+        self.declared, self.in_final = 0, False
+        return h

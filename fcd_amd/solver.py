@@ -120,15 +120,28 @@ class FusedAdam(torch.optim.Optimizer):
                 torch.autograd.graph.increment_version(p)    # raw-pointer update: invalidate packed copies
         return loss
 
+    def load_state_dict(self, state_dict):
+        """The loaded per-parameter moments are copied into the flat buffers at the next arena step."""
+        super().load_state_dict(state_dict)
+        self._flat_state = None
+
     def _step_arena(self):
         ar = self.arena
+        if len(self.param_groups) != 1:
+            raise RuntimeError("FusedAdam with an arena takes a single parameter group")
         group = self.param_groups[0]
         if self._flat_state is None:
             m, v = torch.zeros_like(ar.flat), torch.zeros_like(ar.flat)
-            self._flat_state = {"step": 0, "exp_avg": m, "exp_avg_sq": v}
+            step = 0
             for p, off in zip(ar.params, ar.offsets):      # per-parameter views: the usual state_dict layout
-                self.state[p] = {"step": 0, "exp_avg": m[off:off + p.numel()].view(p.shape),
-                                 "exp_avg_sq": v[off:off + p.numel()].view(p.shape)}
+                mv, vv = m[off:off + p.numel()].view(p.shape), v[off:off + p.numel()].view(p.shape)
+                old = self.state.get(p)
+                if old:                                     # state that load_state_dict (or per-parameter steps) left
+                    mv.copy_(old["exp_avg"])
+                    vv.copy_(old["exp_avg_sq"])
+                    step = max(step, int(old["step"]))
+                self.state[p] = {"step": step, "exp_avg": mv, "exp_avg_sq": vv}
+            self._flat_state = {"step": step, "exp_avg": m, "exp_avg_sq": v}
         fs = self._flat_state
         fs["step"] += 1
         b1, b2 = group["betas"]
@@ -166,6 +179,10 @@ class FCDSolver(nn.Module):
         self.alpha_override: Optional[torch.Tensor] = None   # inject alpha (fcd_solver.py:296) for parity tests
         self.grad_sync = None                       # parallel.GradSync when data-parallel
         self.overlap_comm = True                    # overlap D's gradient all-reduce with the G step's start
+        self.bucket_overlap = True                  # send gradient spans to the all-reduce from inside backward
+        self.bucket_mb = (64.0, 8.0)                # span sizes for (D: 179 MB of gradients, G: 33.8 MB)
+        self._reducers = {}
+        self._scheds = None
         self.pair_g_calls = True                    # G step: the four generator calls as two paired-batch calls
         self.pair_d_calls = True                    # D step: D(x_real) and D(x_fake) as one paired-batch call
         self._pending = None
@@ -226,7 +243,7 @@ class FCDSolver(nn.Module):
     def gradient_penalty(self, y, x):
         """Compute gradient penalty: (L2_norm(dy/dx) - 1)**2."""
         weight = torch.ones(y.size(), device=y.device)
-        with input_grad_only():
+        with input_grad_only(self.D):
             dydx = torch.autograd.grad(outputs=y, inputs=x, grad_outputs=weight, retain_graph=True,
                                        create_graph=True, only_inputs=True)[0]
         return losses.gp_loss(dydx.view(dydx.size(0), -1))
@@ -361,7 +378,26 @@ class FCDSolver(nn.Module):
         if self._opts is None:
             od, og = self.configure_optimizers(arenas=self.device.type == "cuda")
             self._opts = (od["optimizer"], og["optimizer"])
+            self._scheds = (od["lr_scheduler"]["scheduler"], og["lr_scheduler"]["scheduler"])
         return self._opts
+
+    def _grad_passes(self, batch, optimizer_idx: int) -> int:
+        """How many backward passes of this optimizer step produce gradients of the trained network
+        (the last one completes them): D step -- D's backward for (x_real, x_fake) [one paired call or
+        two] plus the gradient penalty's backward-of-backward; G step -- one pass through G per
+        generator call [two paired calls or four]."""
+        x_real = batch[0]
+        if optimizer_idx == 0:
+            return 2 if (self.pair_d_calls and self._pair_fits(x_real, self.d_conv_dim // 4)) else 3
+        return 2 if (self.pair_g_calls and self._pair_fits(x_real, self.g_conv_dim)) else 4
+
+    def _reducer(self, optimizer_idx: int, arena):
+        key = (optimizer_idx, id(arena), id(self.grad_sync), self.bucket_mb[optimizer_idx])
+        r = self._reducers.get(optimizer_idx)
+        if r is None or r[0] != key:
+            r = (key, self.grad_sync.bucketed(arena, self.bucket_mb[optimizer_idx]))
+            self._reducers[optimizer_idx] = r
+        return r[1]
 
     def _flush_pending(self, *_):
         """Finish a deferred D update: wait for its gradient all-reduce, Adam step, clear the arena."""
@@ -385,15 +421,35 @@ class FCDSolver(nn.Module):
         try:
             loss = self.training_step(batch, batch_idx, optimizer_idx)
             if loss is not None:
-                loss.backward()
                 arena = opt.arena if opt.arena is not None and opt.arena.intact() else None
+                handle = None
+                if arena is None:
+                    loss.backward()
+                elif self.grad_sync is not None and self.bucket_overlap and hasattr(self.grad_sync, "bucketed"):
+                    # gradient spans go to the all-reduce from inside the last backward pass through `mine`
+                    red = self._reducer(optimizer_idx, arena)
+                    red.begin(self._grad_passes(batch, optimizer_idx))
+                    mine._grad_hook = red
+                    try:
+                        with arena.accumulating():
+                            loss.backward()
+                    finally:
+                        mine._grad_hook = None
+                    handle = red.finish_rest()
+                else:
+                    with arena.accumulating():      # backward kernels add into p.grad (the arena) themselves
+                        loss.backward()
                 if self.grad_sync is not None:
                     if arena is not None and optimizer_idx == 0 and self.overlap_comm:
                         # D's gradient all-reduce (the large one) runs beside the generator forwards
                         # that open the G step; D is updated right before it is next used
-                        self._pending = (self.grad_sync.allreduce_flat_async(arena.grad), opt, step)
+                        if handle is None:
+                            handle = self.grad_sync.allreduce_flat_async(arena.grad)
+                        self._pending = (handle, opt, step)
                         return loss
-                    if arena is not None:
+                    if handle is not None:
+                        self.grad_sync.finish(handle)
+                    elif arena is not None:
                         self.grad_sync.allreduce_flat(arena.grad)
                     else:
                         self.grad_sync.allreduce([p for p in mine.parameters() if p.grad is not None])
@@ -429,6 +485,7 @@ class FCDSolver(nn.Module):
         x_real, target = batch[0], batch[-1]
         dev = self.device
         if self._val_cm is None:
+            self.sync_running_stats()
             self._val_cm = torch.zeros((2, 2), dtype=torch.int64, device=dev)
             self._val_thr = torch.tensor([self.threshold], dtype=torch.float32, device=dev)
         difference = self.compute_difference_map(x_real.to(dev))
@@ -437,10 +494,34 @@ class FCDSolver(nn.Module):
     def validation_epoch_end(self, val_step_outputs=None):
         """Confusion matrix ``cm[truth][prediction]`` and the reference's printed metrics
         (``fcd_solver.py:523-544``, ``metrics.py``); resets the accumulator."""
+        if self._val_cm is not None and self.grad_sync is not None:
+            # torchmetrics sums its states over ranks at compute() (fcd_solver.py:523-544)
+            self.grad_sync.sum_counts(self._val_cm)
         cm = np.zeros((2, 2), dtype=np.int64) if self._val_cm is None else self._val_cm.cpu().numpy()
         self._val_cm = None
         # the figures of the reference's "Validation Result" line (metrics.accuracy / iou_score / f1_score)
-        return {"confusion_matrix": cm, "Accuracy": accuracy(cm), "IoU": iou_score(cm), "F1": f1_score(cm)}
+        res = {"confusion_matrix": cm, "Accuracy": accuracy(cm), "IoU": iou_score(cm), "F1": f1_score(cm)}
+        if self._scheds is not None:
+            # Lightning steps both ReduceLROnPlateau schedulers on the monitored 'val/F1Score'
+            # (fcd_solver.py:184-199) after every validation epoch
+            for sched in self._scheds:
+                sched.step(res["F1"])
+        return res
+
+    def sync_running_stats(self) -> None:
+        """Data parallel: give every rank rank 0's tracked InstanceNorm running statistics (what DDP's
+        ``broadcast_buffers`` keeps true in the reference) before they are read: eval-mode forwards,
+        validation, threshold search, checkpointing.  A no-op on one rank."""
+        if self.grad_sync is not None and hasattr(self.grad_sync, "broadcast_buffers"):
+            self._flush_pending()
+            self.grad_sync.broadcast_buffers([self.G])
+
+    def state_dict(self, *args, **kwargs):
+        """``G.*`` / ``D.*`` entries as in the reference's checkpoints, with the up-to-date D (a deferred
+        update is finished first).  Data parallel: call :meth:`sync_running_stats` on ALL ranks before
+        rank 0 saves (it is a collective, so it is not hidden in here)."""
+        self._flush_pending()
+        return super().state_dict(*args, **kwargs)
 
     # ---------------------------------------------------------------- inference ---------
     @torch.no_grad()
@@ -464,22 +545,30 @@ class FCDSolver(nn.Module):
 
         Same semantics as the reference (``fcd_solver.py:729-799``): ``G.eval()``, difference map,
         ``> threshold`` -> uint8, ``+1``, invalid (``mask == 0``) -> 0.  Returns the stacked uint8
-        masks; writing HDF5/tiff files is the caller's business (storage is out of the hot path)."""
+        masks -- the (N, H, W) array the reference writes to ``pseudo_masks.h5:/train/masks``
+        (``:785-788``); the confusion matrix it accumulates alongside (``:764-769``) is left in
+        ``self.pseudo_mask_cm``.  Writing HDF5/tiff files is the caller's business (storage is out of
+        the hot path)."""
         if dataset is None:
             raise ValueError("make_psuedo_masks needs an iterable of samples")
         if threshold is None:
             threshold = self.find_best_threshold(dataset=dataset)[0]
         self.G.eval()
-        out = []
+        self.sync_running_stats()
+        out, cm = [], None
         for sample in dataset:
             inputs = sample["image"].to(self.device)
-            _, m = self.difference_and_mask(inputs, threshold)
-            m = m + 1
+            diff = self.compute_difference_map(inputs)
+            target = None
             if "mask" in sample:
-                valid = sample["mask"].to(self.device) > 0
-                m[~valid] = 0
-            out.append(m.cpu())
-        return torch.cat(out).numpy()
+                target = sample["mask"].to(self.device).to(torch.uint8).contiguous()
+                if cm is None:
+                    cm = torch.zeros((2, 2), dtype=torch.int64, device=self.device)
+            # threshold, confusion counts, +1 and invalid -> 0 in one launch; masks stay on the device
+            # until the loop is done (no per-batch device-to-host copy)
+            out.append(ops.pseudo_mask(diff, target, float(threshold), cm=cm if target is not None else None))
+        self.pseudo_mask_cm = None if cm is None else cm.cpu().numpy()     # cm[truth][prediction], fcd_solver.py:764-769
+        return torch.cat(out).cpu().numpy()
 
     generate_masks = make_psuedo_masks
 
@@ -493,6 +582,7 @@ class FCDSolver(nn.Module):
         ``preds > threshold`` is done in fp32 with the threshold rounded to fp32, as numpy 1.x
         (the reference's era) does for a float32 array against a float64 scalar."""
         self.G.eval()
+        self.sync_running_stats()
         dev = self.device
         diffs, targets = [], []
         minmax = torch.tensor([float("inf"), 0.0], dtype=torch.float32, device=dev)

@@ -61,3 +61,132 @@ def test_gradsync_world2_gloo():
     out = mgr.dict()
     mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     assert out[0] and out[1]
+
+
+def _reducer_worker(rank, world, port, out):
+    """BucketedReducer on CPU tensors over gloo: spans go out as soon as their last parameter is
+    reported in the final pass; results equal the plain mean; too many passes raise."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from fcd_amd.arena import ParamArena
+    from fcd_amd.parallel import GradSync
+    shapes = [(40, 3), (7,), (300, 10), (64,), (50, 50), (5,)]
+    ps = [torch.nn.Parameter(torch.zeros(s)) for s in shapes]
+    ar = ParamArena(ps)
+    sync = GradSync(bucket_mb=1.0)
+    red = sync.bucketed(ar, bucket_mb=2000 * 4 / (1 << 20))       # spans of >= 2000 elements, built from the end
+    ok = len(red.spans) >= 3 and red.spans[0][1] == ar.flat.numel() and red.spans[-1][0] == 0
+    ok = ok and all(red.spans[i][0] == red.spans[i + 1][1] for i in range(len(red.spans) - 1))
+
+    def fill(seed_base, scale=1.0):
+        gen = torch.Generator().manual_seed(seed_base + rank)
+        for p_ in ps:
+            p_.grad.add_(torch.randn(p_.shape, generator=gen) * scale)
+
+    def expected(seed_bases):
+        exp = [torch.zeros(s) for s in shapes]
+        for r in range(world):
+            for sb in seed_bases:
+                g2 = torch.Generator().manual_seed(sb + r)
+                for e in exp:
+                    e += torch.randn(e.shape, generator=g2) / world
+        return exp
+
+    # two passes; only the second may send.  Pass 1 reports nothing final.
+    red.begin(2)
+    with ar.accumulating():
+        first = red.pass_begin()
+        fill(100)
+        for p_ in reversed(ps):
+            red.param_ready(p_)              # ignored: not the final pass
+        sent_in_first = len(red.handle)
+        final = red.pass_begin()
+        fill(200)
+        fired_after = []
+        for p_ in reversed(ps):
+            red.param_ready(p_)
+            fired_after.append(red.fired_early)
+    sync.finish(red.finish_rest())
+    ok = ok and (not first) and final and sent_in_first == 0
+    ok = ok and fired_after[-1] == len(red.spans) and fired_after[0] < fired_after[-1]   # spread over the pass
+    exp = expected([100, 200])
+    ok = ok and all(torch.allclose(p_.grad, e, atol=1e-6) for p_, e in zip(ps, exp)) and ar.intact()
+    # a pass outside accumulating() never sends early (autograd would deliver the gradients later)
+    ar.zero_grad()
+    red.begin(1)
+    early_outside = red.pass_begin()
+    fill(300)
+    for p_ in ps:
+        red.param_ready(p_)
+    n_early = red.fired_early
+    sync.finish(red.finish_rest())
+    ok = ok and not early_outside and n_early == 0
+    ok = ok and all(torch.allclose(p_.grad, e, atol=1e-6) for p_, e in zip(ps, expected([300])))
+    # forward-order reporting (the GP's backward-of-backward walks D upwards) still covers every span
+    ar.zero_grad()
+    red.begin(1)
+    with ar.accumulating():
+        red.pass_begin()
+        fill(400)
+        for p_ in ps:
+            red.param_ready(p_)
+    sync.finish(red.finish_rest())
+    ok = ok and all(torch.allclose(p_.grad, e, atol=1e-6) for p_, e in zip(ps, expected([400])))
+    # more passes than declared: spans may already be gone -> loud failure
+    red.begin(1)
+    with ar.accumulating():
+        red.pass_begin()
+        try:
+            red.pass_begin()
+            raised = False
+        except RuntimeError:
+            raised = True
+    sync.finish(red.finish_rest())
+    ok = ok and raised
+    # buffers: rank 0's values everywhere; counts: summed
+    bn = torch.nn.BatchNorm1d(6)
+    with torch.no_grad():
+        bn.running_mean.fill_(float(rank + 1))
+        bn.running_var.fill_(float(10 * (rank + 1)))
+    sync.broadcast_buffers([bn])
+    ok = ok and bool((bn.running_mean == 1.0).all()) and bool((bn.running_var == 10.0).all())
+    cm = torch.tensor([[1, 2], [3, 4]], dtype=torch.int64) * (rank + 1)
+    sync.sum_counts(cm)
+    ok = ok and cm.tolist() == [[3, 6], [9, 12]]
+    out[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_bucketed_reducer_world2_gloo():
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_reducer_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert out[0] and out[1]
+
+
+def test_patch_loader_ranks_partition_one_permutation():
+    """world_size > 1: every rank draws the same seed+epoch permutation, so the rank-strided slices
+    are disjoint and cover the pool (DistributedSampler semantics), and epochs differ."""
+    from fcd_amd.data_loader import PatchLoader
+
+    class _Pool:
+        def __init__(self, n):
+            self.n = n
+
+        def __len__(self):
+            return self.n
+
+        def gather(self, pos, aug, ret_mask):
+            return pos.clone()
+
+    n, world = 37, 2
+    seen = []
+    for epoch_loaders in [[PatchLoader(_Pool(n), batch_size=5, mode="train", rank=r, world_size=world, seed=11,
+                                       generator=torch.Generator().manual_seed(1000 + r)) for r in range(world)]]:
+        for _ in range(2):
+            per_rank = [torch.cat(list(iter(ld))) for ld in epoch_loaders]
+            allpos = torch.cat(per_rank)
+            assert allpos.numel() == 38 and set(allpos.tolist()) == set(range(n))     # one wrap-around duplicate
+            assert len(set(per_rank[0].tolist()) & set(per_rank[1].tolist())) <= 1
+            seen.append(per_rank[0].tolist())
+    assert seen[0] != seen[1]
