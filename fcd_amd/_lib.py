@@ -103,6 +103,9 @@ PROTOTYPES = {
     "fcd_adam_step": (_I, [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _I, _P]),
     "fcd_diffmap_threshold": (_I, [_P, _P, _P, _P, _F, _I, _I, _I, _I, _P]),
     "fcd_scene_tiles": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _P, _P]),
+    "fcd_scene_tile_valid": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _P]),
+    "fcd_scene_tif_bytes": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
+    "fcd_pseudo_mask": (_I, [_P, _P, C.c_size_t, _F, _P, _P, _P]),
     "fcd_scene_stitch": (_I, [_P, _P, _I, _I, _P, _I, _I, _P]),
     "fcd_scene_binarize": (_I, [_P, _P, _I, _I, _I, C.c_double, _P, _P]),
     "fcd_patch_batch": (_I, [_P, C.c_long, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P]),

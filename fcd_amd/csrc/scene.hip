@@ -165,6 +165,82 @@ __global__ __launch_bounds__(256) void patch_batch_kernel(const uint16_t* __rest
   }
 }
 
+// One block per tile: valid[b] = 1 if any band of any pixel of the (reflect-padded) tile is non-zero --
+// the all-nodata test of evaluate.py:104 for every tile of a scene in one launch.
+__global__ __launch_bounds__(256) void scene_tile_valid_kernel(const uint16_t* __restrict__ scene, int H, int W, int C,
+                                                               int patch, const int* __restrict__ origins,
+                                                               uint8_t* __restrict__ valid) {
+  const int b = blockIdx.x;
+  const int r0 = origins[2 * b], c0 = origins[2 * b + 1];
+  // reflected rows / columns repeat rows / columns of the scene that the tile already covers or that lie
+  // just inside the edge, so the tile's in-scene part plus the mirrored strip decide; walking the
+  // padded index space keeps this the same predicate as scene_tiles_kernel's
+  const int row_elems = patch * C;
+  int seen = 0;
+  for (int py = 0; py < patch && !seen; ++py) {
+    int r = r0 + py;
+    r = r < H ? r : 2 * (H - 1) - r;
+    for (int e = threadIdx.x; e < row_elems; e += 256) {
+      int c = c0 + e / C;
+      c = c < W ? c : 2 * (W - 1) - c;
+      seen |= scene[((long)r * W + c) * C + e % C] != 0;
+    }
+    seen = __syncthreads_or(seen);
+  }
+  if (threadIdx.x == 0) valid[b] = seen ? 1 : 0;
+}
+
+// make_psuedo_masks' per-batch tail (fcd_solver.py:762-772): pseudo = (diff > thr) compared in fp32,
+// confusion counts over valid pixels, then pseudo + 1 with invalid pixels (target == 0) set to 0.
+__global__ __launch_bounds__(256) void pseudo_mask_kernel(const float* __restrict__ diff, const uint8_t* __restrict__ target,
+                                                          size_t n, float thr, uint8_t* __restrict__ out,
+                                                          unsigned long long* __restrict__ cm) {
+  __shared__ unsigned sc[4];
+  if (threadIdx.x < 4) sc[threadIdx.x] = 0u;
+  __syncthreads();
+  // at most 2^22 pixels per block keep the 32-bit LDS counters exact
+  const size_t per_block = ((n + gridDim.x - 1) / gridDim.x + 255) / 256 * 256;
+  const size_t begin = (size_t)blockIdx.x * per_block;
+  const size_t end = begin + per_block < n ? begin + per_block : n;
+  unsigned c[4] = {0u, 0u, 0u, 0u};
+  for (size_t i = begin + threadIdx.x; i < end; i += 256) {
+    const int pred = diff[i] > thr ? 1 : 0;
+    const int tg = target ? target[i] : 1;
+    out[i] = tg == 0 ? (uint8_t)0 : (uint8_t)(pred + 1);
+    if (tg != 0) c[(tg > 1 ? 2 : 0) + pred] += 1u;
+  }
+  if (cm) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      unsigned v = c[k];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      if ((threadIdx.x & 63) == 0 && v) atomicAdd(&sc[k], v);
+    }
+    __syncthreads();
+    if (threadIdx.x < 4 && sc[threadIdx.x]) atomicAdd(&cm[threadIdx.x], (unsigned long long)sc[threadIdx.x]);
+  }
+}
+
+// write_tifs' byte rasters (evaluate.py:384-390): difference * 255 truncated to uint8, and the
+// prediction as 128 (clear) / 255 (cloudy) with invalid pixels 0.
+__global__ __launch_bounds__(256) void scene_tif_kernel(const double* __restrict__ raster, const uint8_t* __restrict__ pred,
+                                                        const uint8_t* __restrict__ valid, const uint16_t* __restrict__ scene,
+                                                        long npix, int C, uint8_t* __restrict__ diff_u8,
+                                                        uint8_t* __restrict__ mask_u8) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < npix; i += (long)gridDim.x * 256) {
+    int ok;
+    if (valid) {
+      ok = valid[i] != 0;
+    } else {
+      ok = 0;
+      for (int k = 0; k < C; ++k) ok |= scene[i * C + k] != 0;
+    }
+    if (diff_u8) diff_u8[i] = (uint8_t)(long)(raster[i] * 255.0);     // numpy astype(uint8) of a float64 in [0, 256)
+    if (mask_u8) mask_u8[i] = ok ? (pred[i] ? 255 : 128) : 0;
+  }
+}
+
 inline int grid_for(size_t n, int cap = 8192) {
   const size_t b = (n + 255) / 256;
   return (int)(b < 1 ? 1 : (b > (size_t)cap ? cap : b));
@@ -181,6 +257,37 @@ extern "C" int fcd_scene_tiles(const uint16_t* scene, int H, int W, int C, int p
   hipLaunchKernelGGL(scene_tiles_kernel, dim3(grid_for((size_t)nb * patch * patch)), dim3(256), 0, fcd_stream(stream), scene,
                      H, W, C, patch, origins_rc, nb, x_nchw, any_valid);
   return fcd_check_launch("scene_tiles");
+}
+
+extern "C" int fcd_scene_tile_valid(const uint16_t* scene, int H, int W, int C, int patch, const int* origins_rc, int nb,
+                                    uint8_t* valid, void* stream) {
+  FCD_REQUIRE(scene && origins_rc && valid, "scene_tile_valid: null pointer");
+  FCD_REQUIRE(H > 0 && W > 0 && C > 0 && patch > 0 && nb > 0, "scene_tile_valid: bad extents");
+  FCD_REQUIRE(patch <= H - 1 && patch <= W - 1, "scene_tile_valid: scene %dx%d smaller than patch %d + 1", H, W, patch);
+  hipLaunchKernelGGL(scene_tile_valid_kernel, dim3(nb), dim3(256), 0, fcd_stream(stream), scene, H, W, C, patch, origins_rc,
+                     valid);
+  return fcd_check_launch("scene_tile_valid");
+}
+
+extern "C" int fcd_pseudo_mask(const float* diff, const uint8_t* target, size_t n, float thr, uint8_t* out,
+                               unsigned long long* cm, void* stream) {
+  FCD_REQUIRE(diff && out && n > 0, "pseudo_mask: bad arguments");
+  int blocks = grid_for(n, 2048);
+  const size_t min_blocks = (n + ((size_t)1 << 22) - 1) >> 22;
+  if ((size_t)blocks < min_blocks) blocks = (int)min_blocks;
+  hipLaunchKernelGGL(pseudo_mask_kernel, dim3(blocks), dim3(256), 0, fcd_stream(stream), diff, target, n, thr, out, cm);
+  return fcd_check_launch("pseudo_mask");
+}
+
+extern "C" int fcd_scene_tif_bytes(const double* raster, const uint8_t* prediction, const uint8_t* valid,
+                                   const uint16_t* scene, int H, int W, int C, uint8_t* diff_u8, uint8_t* mask_u8,
+                                   void* stream) {
+  FCD_REQUIRE(raster && (diff_u8 || mask_u8) && H > 0 && W > 0, "scene_tif_bytes: bad arguments");
+  FCD_REQUIRE(!mask_u8 || (prediction && (valid || (scene && C > 0))),
+              "scene_tif_bytes: the mask needs the prediction and a validity source (valid mask or the scene)");
+  hipLaunchKernelGGL(scene_tif_kernel, dim3(grid_for((size_t)H * W)), dim3(256), 0, fcd_stream(stream), raster, prediction,
+                     valid, scene, (long)H * W, C, diff_u8, mask_u8);
+  return fcd_check_launch("scene_tif_bytes");
 }
 
 extern "C" int fcd_scene_stitch(const float* delta, const int* origins_rc, int nb, int patch, double* raster, int H, int W,

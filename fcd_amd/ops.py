@@ -558,6 +558,63 @@ def scene_tiles(scene: torch.Tensor, origins: torch.Tensor, patch: int):
     return x, flag
 
 
+def scene_tile_valid(scene: torch.Tensor, origins: torch.Tensor, patch: int) -> torch.Tensor:
+    """(nb,) uint8 on the device: 1 where tile b of the scene holds any non-zero sample."""
+    L.require_gpu_tensor(scene, "scene", torch.uint16)
+    L.require_gpu_tensor(origins, "origins", torch.int32)
+    h, w, c = scene.shape
+    nb = origins.shape[0]
+    valid = torch.empty((nb,), dtype=torch.uint8, device=scene.device)
+    check(L.load().fcd_scene_tile_valid(ptr(scene), h, w, c, patch, ptr(origins), nb, ptr(valid), stream()), "scene_tile_valid")
+    return valid
+
+
+def scene_tif_bytes(raster: torch.Tensor, prediction: Optional[torch.Tensor], valid: Optional[torch.Tensor] = None,
+                    scene: Optional[torch.Tensor] = None, want_diff: bool = True):
+    """``write_tifs``' byte rasters: ((difference * 255) as uint8, mask in {0, 128, 255}); either may be None."""
+    h, w = raster.shape
+    L.require_gpu_tensor(raster, "raster", torch.float64)
+    for t, nm in ((prediction, "prediction"), (valid, "valid")):
+        if t is not None:
+            L.require_gpu_tensor(t, nm, torch.uint8)
+            if tuple(t.shape) != (h, w):
+                raise RuntimeError(f"scene_tif_bytes: {nm} must be (H, W)")
+    c = 0
+    if scene is not None:
+        L.require_gpu_tensor(scene, "scene", torch.uint16)
+        if tuple(scene.shape[:2]) != (h, w):
+            raise RuntimeError("scene_tif_bytes: scene must be (H, W, C)")
+        c = scene.shape[2]
+    diff_u8 = torch.empty((h, w), dtype=torch.uint8, device=raster.device) if want_diff else None
+    mask_u8 = torch.empty((h, w), dtype=torch.uint8, device=raster.device) if prediction is not None else None
+    check(L.load().fcd_scene_tif_bytes(ptr(raster), ptr(prediction), ptr(valid), ptr(scene), h, w, c, ptr(diff_u8),
+                                       ptr(mask_u8), stream()), "scene_tif_bytes")
+    return diff_u8, mask_u8
+
+
+def pseudo_mask(diff: torch.Tensor, target: Optional[torch.Tensor], thr: float, out: Optional[torch.Tensor] = None,
+                cm: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``(diff > thr) + 1`` with invalid pixels (``target == 0``) set to 0 (``fcd_solver.py:762-772``);
+    ``cm`` (2, 2) int64 on the device, when given, gets the confusion counts of the valid pixels added."""
+    L.require_gpu_tensor(diff, "diff")
+    if target is not None:
+        L.require_gpu_tensor(target, "target", torch.uint8)
+        if target.numel() != diff.numel():
+            raise RuntimeError("pseudo_mask: target and diff differ in size")
+    if out is None:
+        out = torch.empty(diff.shape, dtype=torch.uint8, device=diff.device)
+    else:
+        L.require_gpu_tensor(out, "out", torch.uint8)
+        if out.numel() != diff.numel():
+            raise RuntimeError("pseudo_mask: out and diff differ in size")
+    if cm is not None:
+        L.require_gpu_tensor(cm, "cm", torch.int64)
+        if cm.numel() != 4:
+            raise RuntimeError("pseudo_mask: cm must be (2, 2) int64")
+    check(L.load().fcd_pseudo_mask(ptr(diff), ptr(target), diff.numel(), float(thr), ptr(out), ptr(cm), stream()), "pseudo_mask")
+    return out
+
+
 def scene_stitch(delta: torch.Tensor, origins: torch.Tensor, raster: torch.Tensor) -> None:
     nb, patch, _ = delta.shape
     h, w = raster.shape

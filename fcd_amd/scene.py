@@ -38,11 +38,15 @@ def _device_scene(full_image: np.ndarray, solver, patch: int, batch_size: int):
     scene = torch.from_numpy(np.ascontiguousarray(full_image)).to(dev)
     org = torch.tensor(origins, dtype=torch.int32, device=dev).view(-1, 2)
     raster = torch.zeros((h, w), dtype=torch.float64, device=dev)
+    # don't waste time on invalid patches (evaluate.py:104: a batch whose samples are all nodata is
+    # skipped): the flags of every tile come from one launch and one copy per scene, taken while the
+    # queue is still empty, instead of a device-to-host sync in front of every batch
+    tile_valid = ops.scene_tile_valid(scene, org, patch).cpu().numpy()
     for s in range(0, len(origins), batch_size):
-        o = org[s:s + batch_size].contiguous()
-        x, any_valid = ops.scene_tiles(scene, o, patch)
-        if int(any_valid.item()) == 0:     # don't waste time on invalid patches (evaluate.py:104)
+        if not tile_valid[s:s + batch_size].any():
             continue
+        o = org[s:s + batch_size].contiguous()
+        x, _ = ops.scene_tiles(scene, o, patch)
         ops.scene_stitch(solver.compute_difference_map(x), o, raster)
     return scene, raster
 
@@ -79,10 +83,20 @@ def predict_scene_host(full_image: np.ndarray, solver, patch_size: int = None, b
     return difference
 
 
-def generate_scene_mask(full_image: np.ndarray, solver, threshold: float = 0.02, batch_size: int = 64):
-    """difference raster -> nodata zeroed -> ``solver.binarize`` (``evaluate.py:49-51``)."""
+def generate_scene_mask(full_image: np.ndarray, solver, threshold: float = 0.02, batch_size: int = 64,
+                        tif_bytes: bool = False, valid_mask: np.ndarray = None):
+    """difference raster -> nodata zeroed -> ``solver.binarize`` (``evaluate.py:49-51``).
+
+    ``tif_bytes``: also return what ``write_tifs`` stores (``evaluate.py:384-390``):
+    ``(difference * 255).astype(uint8)`` and the prediction as 128 / 255 with invalid pixels 0, where
+    valid is ``valid_mask`` ((H, W) bool, the reference passes ``target > 0``) or, without one,
+    "any band non-zero"."""
     from . import ops
     with torch.no_grad():
         scene, raster = _device_scene(full_image, solver, solver.image_size, batch_size)
         mask = ops.scene_binarize(raster, scene, threshold)
+        if tif_bytes:
+            vm = None if valid_mask is None else torch.from_numpy(np.ascontiguousarray(valid_mask).astype(np.uint8)).to(mask.device)
+            diff_u8, mask_u8 = ops.scene_tif_bytes(raster, mask, vm, scene)
+            return raster.cpu().numpy(), mask.cpu().numpy(), diff_u8.cpu().numpy(), mask_u8.cpu().numpy()
     return raster.cpu().numpy(), mask.cpu().numpy()

@@ -288,6 +288,11 @@ int fcd_adam_step(float* p, const float* g, float* m, float* v, size_t n, float 
  * ------------------------------------------------------------------------- */
 int fcd_diffmap_threshold(const float* x_fake, const float* x, float* diff, uint8_t* mask,
                           float thr, int N, int C, int H, int W, void* stream);
+/* make_psuedo_masks' per-batch tail (fcd_solver.py:762-772) in one pass: pseudo = diff > thr (fp32
+ * compare); cm[truth][pred] += counts over valid pixels (target 1 = clear, 2 = cloudy; cm is 4 device
+ * uint64, may be NULL); out = pseudo + 1, invalid pixels (target == 0) -> 0.  target NULL: all valid. */
+int fcd_pseudo_mask(const float* diff, const uint8_t* target, size_t n, float thr, uint8_t* out,
+                    unsigned long long* cm, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Scene path on the device.
@@ -308,6 +313,17 @@ int fcd_scene_tiles(const uint16_t* scene, int H, int W, int C, int patch, const
                     float* x_nchw, int* any_valid, void* stream);
 int fcd_scene_stitch(const float* delta, const int* origins_rc, int nb, int patch, double* raster, int H,
                      int W, void* stream);
+/* valid[b] = 1 if tile b (origin origins_rc[b], reflect padding as fcd_scene_tiles) holds any non-zero
+ * sample: the all-nodata test of evaluate.py:104 for every tile of a scene in ONE launch, so that the
+ * caller decides which batches to skip with one device-to-host copy per scene instead of one per batch. */
+int fcd_scene_tile_valid(const uint16_t* scene, int H, int W, int C, int patch, const int* origins_rc, int nb,
+                         uint8_t* valid, void* stream);
+/* write_tifs' byte rasters (evaluate.py:384-390): diff_u8 = (difference * 255).astype(uint8);
+ * mask_u8 = 128 where prediction == 0, 255 where prediction == 1, 0 where not valid.  valid[H][W]
+ * (uint8, e.g. target > 0) or, when NULL, "any band of scene != 0".  Either output may be NULL. */
+int fcd_scene_tif_bytes(const double* raster, const uint8_t* prediction, const uint8_t* valid,
+                        const uint16_t* scene, int H, int W, int C, uint8_t* diff_u8, uint8_t* mask_u8,
+                        void* stream);
 int fcd_scene_binarize(double* raster, const uint16_t* scene, int H, int W, int C, double threshold,
                        uint8_t* mask, void* stream);
 

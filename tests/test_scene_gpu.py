@@ -48,6 +48,8 @@ def test_pseudo_masks_encoding(dev):
     far = (d - 0.02794).abs().numpy() > 1e-5
     assert np.array_equal(m[far], ref[far])
     assert s.generate_masks.__func__ is s.make_psuedo_masks.__func__
+    assert s.pseudo_mask_cm.shape == (2, 2) and int(s.pseudo_mask_cm.sum()) == int(valid.sum())
+    assert int(s.pseudo_mask_cm[1].sum()) == 0                      # every valid pixel of this target is "clear"
 
 
 def _scene(h, w, seed=5):
@@ -172,3 +174,80 @@ def test_validation_step_confusion_matrix(dev):
     assert out["F1"] == O.f1_score(cm_ref)
     assert abs(out["Accuracy"] - np.diag(cm_ref).sum() / cm_ref.sum()) < 1e-15
     assert s.validation_epoch_end()["confusion_matrix"].sum() == 0      # accumulator was reset
+
+
+def test_scene_at_stated_size_device_equals_host(dev):
+    """BASELINE.json configs[3] at its stated size: a 2000 x 1900 x 10 synthetic scene (not a multiple of
+    the patch: reflect padding on both edges), 128x128 patches, batch 64, the full-size generator.
+    Device path == host (reference-style numpy tiling / stitching) path bit for bit, the mask == numpy's
+    float64 '>' on the raster, all-nodata batches are skipped on both sides (the first batch of 64 tiles
+    is nodata), and the write_tifs byte rasters equal numpy's."""
+    from fcd_amd import FCDSolver, ops
+    from fcd_amd.scene import generate_scene_mask, predict_scene_host, scene_patches
+    h, w = 2000, 1900
+    rng = np.random.default_rng(4)
+    sc = rng.integers(1, 65536, size=(h, w, 10), dtype=np.uint16)
+    sc[:700] = 0                      # more than the first 64 tiles (4.27 tile rows): batch 0 is skipped
+    sc[:, :48] = 0
+    sc[-30:] = 0
+    s = FCDSolver(None, precision="fp32x3")
+    s.G.load_state_dict(O.synth_generator_state())
+    s.to(dev)
+    s.G.eval()
+    # per-tile nodata flags against numpy on the reflect-padded scene
+    origins, pad_h, pad_w, _ = scene_patches(h, w, 128, 0)
+    assert len(origins) == 16 * 15
+    padded = np.pad(sc, (pad_h, pad_w, (0, 0)), "reflect")
+    ref_valid = np.array([padded[r:r + 128, c:c + 128].any() for r, c in origins], dtype=np.uint8)
+    tv = ops.scene_tile_valid(torch.from_numpy(sc).to(dev), torch.tensor(origins, dtype=torch.int32, device=dev), 128)
+    assert np.array_equal(tv.cpu().numpy(), ref_valid) and not ref_valid[:64].any() and ref_valid[64:].any()
+    calls = []
+    orig = s.compute_difference_map
+    s.compute_difference_map = lambda x: (calls.append(x.shape[0]), orig(x))[1]
+    d, m, du8, mu8 = generate_scene_mask(sc, s, 0.02, batch_size=64, tif_bytes=True)
+    assert calls == [64, 64, 48]      # 240 tiles in batches of 64, the first one skipped
+    s.compute_difference_map = orig
+    ref = predict_scene_host(sc, s, batch_size=64)
+    valid = np.any(sc != 0, axis=2)
+    ref[~valid] = 0
+    assert d.dtype == np.float64 and np.array_equal(d, ref)
+    assert np.array_equal(m, (ref > 0.02).astype(np.uint8)) and 0 < int(m.sum()) < valid.sum()
+    # evaluate.py:384-390
+    assert np.array_equal(du8, (ref * 255).astype(np.uint8))
+    tif = m.copy()
+    tif[tif == 0] = 128
+    tif[tif == 1] = 255
+    tif[~valid] = 0
+    assert np.array_equal(mu8, tif) and set(np.unique(mu8).tolist()) == {0, 128, 255}
+    # an explicit validity mask (the reference passes target > 0)
+    vm = valid.copy()
+    vm[1000:1100] = False
+    _, _, _, mu8b = generate_scene_mask(sc, s, 0.02, batch_size=64, tif_bytes=True, valid_mask=vm)
+    tif[~vm] = 0
+    assert np.array_equal(mu8b, tif)
+
+
+def test_pseudo_mask_kernel_counts_and_encoding(dev):
+    """fcd_pseudo_mask: threshold + confusion counts + {0, 1, 2} encoding in one pass == numpy
+    (fcd_solver.py:762-772), incl. values exactly at fp32(thr)."""
+    from fcd_amd import ops
+    rng = np.random.default_rng(21)
+    n = 3 * 128 * 128 + 17
+    thr = 0.02794
+    d = rng.random(n).astype(np.float32) * 0.06
+    t32 = np.float32(thr)
+    d[:6] = [t32, np.nextafter(t32, np.float32(1)), np.nextafter(t32, np.float32(0)), 0.0, 1.0, t32]
+    tgt = rng.integers(0, 3, size=n).astype(np.uint8)
+    cm = torch.zeros((2, 2), dtype=torch.int64, device=dev)
+    out = ops.pseudo_mask(torch.from_numpy(d).to(dev), torch.from_numpy(tgt).to(dev), thr, cm=cm)
+    pred = (torch.from_numpy(d) > thr).numpy().astype(np.uint8)          # torch's fp32 compare
+    ref = pred + 1
+    ref[tgt == 0] = 0
+    assert np.array_equal(out.cpu().numpy(), ref)
+    valid = tgt > 0
+    cm_ref = O.compute_confusion_matrix(pred[valid], tgt[valid] - 1, 2)
+    assert np.array_equal(cm.cpu().numpy(), cm_ref.astype(np.int64))
+    ops.pseudo_mask(torch.from_numpy(d).to(dev), torch.from_numpy(tgt).to(dev), thr, cm=cm)    # accumulates
+    assert np.array_equal(cm.cpu().numpy(), 2 * cm_ref.astype(np.int64))
+    out2 = ops.pseudo_mask(torch.from_numpy(d).to(dev), None, thr)                                   # no target: all valid
+    assert np.array_equal(out2.cpu().numpy(), pred + 1)
