@@ -689,9 +689,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
   // optional InstanceNorm statistics of the tile just computed: per-wave column sums (sum, sum of
   // squares over the wave's WTM rows, which lie in one image), written as double partials for
   // finalize_kernel<FIN_STATS>; saves the separate read of the output tensor
-  float ssum[TN], qsum[TN];
+  // (sums of v - ssh and (v - ssh)^2, ssh = the lane's first value of the column: keeps the variance of a
+  // channel with |mean| >> std out of the fp32 rounding of sum v^2; undone in double below)
+  float ssum[TN], qsum[TN], ssh[TN];
+  int scnt[TN];
 #pragma unroll
-  for (int ni = 0; ni < TN; ++ni) ssum[ni] = qsum[ni] = 0.f;
+  for (int ni = 0; ni < TN; ++ni) { ssum[ni] = qsum[ni] = ssh[ni] = 0.f; scnt[ni] = 0; }
 #pragma unroll
   for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
@@ -738,8 +741,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           if (off[r] >= 0) {
-            ssum[ni] += v[r];
-            qsum[ni] += v[r] * v[r];
+            if (scnt[ni] == 0) ssh[ni] = v[r];
+            ++scnt[ni];
+            const float dv = v[r] - ssh[ni];
+            ssum[ni] += dv;
+            qsum[ni] += dv * dv;
           }
       }
     }
@@ -750,13 +756,16 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
       const long chunk = (long)n * p.nphase * p.stats_cpp + (long)phase * p.stats_cpp + local;
 #pragma unroll
       for (int ni = 0; ni < TN; ++ni) {
-        const float s2 = ssum[ni] + __shfl_xor(ssum[ni], 32);
-        const float q2 = qsum[ni] + __shfl_xor(qsum[ni], 32);
+        const double shd = (double)ssh[ni], cn = (double)scnt[ni];
+        double s2 = (double)ssum[ni] + cn * shd;
+        double q2 = (double)qsum[ni] + 2.0 * shd * (double)ssum[ni] + cn * shd * shd;
+        s2 += __shfl_xor(s2, 32);
+        q2 += __shfl_xor(q2, 32);
         const int co = tn * BN + wn * WTN + ni * 32 + lr;
         if (lh == 0 && co < p.CoutP) {
           double* d2 = p.stats + (chunk * p.CoutP + co) * 2;
-          d2[0] = (double)s2;
-          d2[1] = (double)q2;
+          d2[0] = s2;
+          d2[1] = q2;
         }
       }
     }

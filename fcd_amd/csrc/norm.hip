@@ -80,15 +80,26 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restric
         }
       }
     }
+    // MODE_STATS sums z - sh and (z - sh)^2 with sh = the thread's first value: a channel whose mean is
+    // large against its spread (|mean| >> std) would otherwise lose its variance in the fp32 partial
+    // sums of z^2; the shift is undone in double when the partial is written
+    float sh[4] = {0.f, 0.f, 0.f, 0.f};
+    int cnt = 0;
+    if (MODE == MODE_STATS && p0 + ty < p1) {
+      const float4 f = *reinterpret_cast<const float4*>(x0 + ((long)n * HW + p0 + ty) * C + cbase + tx * 4);
+      sh[0] = f.x; sh[1] = f.y; sh[2] = f.z; sh[3] = f.w;
+    }
     for (long px = p0 + ty; px < p1; px += pl.rows) {
       const long off = ((long)n * HW + px) * C + cbase + tx * 4;
       const float4 a = *reinterpret_cast<const float4*>(x0 + off);
       const float av[4] = {a.x, a.y, a.z, a.w};
       if (MODE == MODE_STATS) {
+        ++cnt;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          s0[e] += av[e];
-          s1[e] += av[e] * av[e];
+          const float dv = av[e] - sh[e];
+          s0[e] += dv;
+          s1[e] += dv * dv;
         }
       } else if (MODE == MODE_SUM) {
 #pragma unroll
@@ -114,8 +125,14 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restric
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      sm[((long)ty * CB + tx * 4 + e) * 2 + 0] = (double)s0[e];
-      sm[((long)ty * CB + tx * 4 + e) * 2 + 1] = (double)s1[e];
+      double d0 = (double)s0[e], d1 = (double)s1[e];
+      if (MODE == MODE_STATS) {      // sum z = sum d + cnt sh;  sum z^2 = sum d^2 + 2 sh sum d + cnt sh^2
+        const double shd = (double)sh[e];
+        d1 += 2.0 * shd * d0 + (double)cnt * shd * shd;
+        d0 += (double)cnt * shd;
+      }
+      sm[((long)ty * CB + tx * 4 + e) * 2 + 0] = d0;
+      sm[((long)ty * CB + tx * 4 + e) * 2 + 1] = d1;
     }
   }
   __syncthreads();

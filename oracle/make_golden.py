@@ -281,8 +281,20 @@ def run_config(cfg, store_tensors, nsamp=64):
                 idx = sample_idx(g32[k].numel(), nsamp)
                 big[f"{tag}.idx.{k}"] = idx.astype(np.int64)
                 big[f"{tag}.ref32.{k}"] = g32[k].flatten()[idx].numpy()
-                big[f"{tag}.ora64.{k}"] = gg = g64[k].flatten()[idx].numpy()
+                big[f"{tag}.ora64.{k}"] = g64[k].flatten()[idx].numpy()
+                # a second, independent sample of the same size (another seed)
+                idx2 = sample_idx(g32[k].numel(), nsamp, seed=1234)
+                big[f"{tag}.idx2.{k}"] = idx2.astype(np.int64)
+                big[f"{tag}.ref32_2.{k}"] = g32[k].flatten()[idx2].numpy()
+                big[f"{tag}.ora64_2.{k}"] = g64[k].flatten()[idx2].numpy()
         out["big_samples"] = big
+        # element-wise companions of the norm-wise figures, over the whole tensors: ||g64||_inf and the
+        # reference-fp32 maximum absolute error relative to it
+        scal["grad_absmax64"] = {tag: {k: float(v.abs().max()) for k, v in g64.items()}
+                                 for tag, g64 in (("d", dg64), ("g", gg64))}
+        scal["ref_fp32_vs_fp64_grad_maxabs_rel"] = {
+            tag: {k: float((g32[k].double() - g64[k]).abs().max() / (g64[k].abs().max() + 1e-300)) for k in g32}
+            for tag, g32, g64 in (("d", d_grads, dg64), ("g", g_grads, gg64))}
     return out
 
 
@@ -413,11 +425,20 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="also the full-size baseline config (scalars only)")
     ap.add_argument("--variants", action="store_true", help="only tests/golden/tiny_variants.npz")
+    ap.add_argument("--full-only", action="store_true", help="only the full-size fixtures (full_scalars.json, full_grad_samples.npz)")
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
     if args.variants:
         np.savez_compressed(os.path.join(GOLD, "tiny_variants.npz"), **run_variants(TINY))
+        return
+
+    if args.full_only:
+        torch.set_num_threads(os.cpu_count())
+        r = run_config(FULL, False, nsamp=4096)
+        json.dump(r["scalars"], open(os.path.join(GOLD, "full_scalars.json"), "w"), indent=1)
+        np.savez_compressed(os.path.join(GOLD, "full_grad_samples.npz"), **r["big_samples"])
+        print("full: worst oracle-vs-reference rel-err", r["scalars"]["oracle_vs_reference_worst_relerr"])
         return
 
     r = run_config(TINY, True)

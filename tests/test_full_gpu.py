@@ -4,7 +4,10 @@ size-independent properties.  Inputs and weights are regenerated from the numpy-
 
 The reference's own fp32 step is ill-conditioned at this size (its fp32 gradients differ from its
 fp64 gradients by up to 3e-3 per tensor), so gradients are judged against
-the fp64 oracle: the HIP error may not exceed max(1e-4, 2 x the reference-fp32 error).
+the fp64 oracle: the HIP error may not exceed max(1e-4, 1.0 x the reference-fp32 error) in the default fp32x3
+mode (2.0 x for the exact-fp32 MFMA chains), norm-wise on two independent samples per tensor, plus an
+element-wise bar (FACTORS below); the measured errors are written to
+gpurun_out/full_parity_{d,g}_{precision}.json (copies under profiles/).
 """
 import json
 import os
@@ -37,16 +40,61 @@ def full(dev):
 
 
 BIG = np.load(os.path.join(GOLD, "full_grad_samples.npz"))
+# The HIP error against the fp64 oracle may not exceed max(1e-4, factor x the reference's own fp32 error) --
+# per tensor, norm-wise on two independent 4096-element samples and element-wise (max |error| / ||g64||_inf
+# against the reference's figure over the whole tensor).  Factors (norm-wise, element-wise) per precision:
+#   fp32x3 (the default / benchmarked mode): 1.0 and 1.5 -- no tensor is further from fp64 than the reference's
+#     own fp32 step is (worst measured ratio 0.89), element-wise within 1.5x (worst 1.37);
+#   fp32 (exact v_mfma_f32_32x32x2_f32 chains): 2.0 and 12 -- a sequential fp32 fma chain over K is a little less
+#     accurate than torch's blocked CPU sums (worst norm-wise ratio 1.73), and the element-wise maximum is an
+#     extreme-value statistic of a step with ReLU / LeakyReLU / L1 kinks: a single activation-mask flip moves a
+#     few elements by O(1) of their value in either fp32 evaluation (worst ratio 9.8, D features.1.0.weight).
+# The measured errors of every tensor are written to gpurun_out/full_parity_*.json.
+FACTORS = {"fp32x3": (1.0, 1.5), "fp32": (2.0, 12.0)}
+OUT_DIR = os.path.join(os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(__file__))), "gpurun_out")
 
 
-def sample_errors(grad, tag, name):
-    """(HIP error, reference-fp32 error) vs the fp64 oracle on the same 4096-element sample."""
-    idx = torch.from_numpy(BIG[f"{tag}.idx.{name}"])
-    o64 = torch.from_numpy(BIG[f"{tag}.ora64.{name}"]).double()
-    r32 = torch.from_numpy(BIG[f"{tag}.ref32.{name}"]).double()
+def sample_errors(grad, tag, name, sc, which=""):
+    """Errors vs the fp64 oracle on one of the two stored samples: (HIP norm-wise, reference-fp32 norm-wise,
+    HIP max-abs / ||g64||_inf, reference-fp32 max-abs / ||g64||_inf over the whole tensor)."""
+    idx = torch.from_numpy(BIG[f"{tag}.idx{which}.{name}"])
+    sfx = "_2" if which == "2" else ""
+    o64 = torch.from_numpy(BIG[f"{tag}.ora64{sfx}.{name}"]).double()
+    r32 = torch.from_numpy(BIG[f"{tag}.ref32{sfx}.{name}"]).double()
     got = grad.detach().flatten().cpu()[idx].double()
     den = float(o64.norm()) + 1e-30
-    return float((got - o64).norm()) / den, float((r32 - o64).norm()) / den
+    amax = sc["grad_absmax64"][tag][name] + 1e-300
+    return (float((got - o64).norm()) / den, float((r32 - o64).norm()) / den,
+            float((got - o64).abs().max()) / amax, sc["ref_fp32_vs_fp64_grad_maxabs_rel"][tag][name])
+
+
+def check_grads(net, tag, sc, prec):
+    FACTOR, FACTOR_MAX = FACTORS[prec]
+    report, worst = {}, 0.0
+    for name, p in net.named_parameters():
+        entry = {}
+        for which in ("", "2"):
+            e, eref, emax, eref_max = sample_errors(p.grad, tag, name, sc, which)
+            bar, bar_max = max(1e-4, FACTOR * eref), max(1e-4, FACTOR_MAX * eref_max)
+            entry["sample" + (which or "1")] = {"hip": e, "ref_fp32": eref, "hip_maxabs": emax, "ref_fp32_maxabs": eref_max}
+            worst = max(worst, e / bar, emax / bar_max)
+            if os.environ.get("FCD_PARITY_SURVEY"):
+                continue
+            assert e <= bar, (name, which, e, eref)
+            assert emax <= bar_max, (name, which, emax, eref_max)
+        n64 = sc[f"{tag}_grad_norm64"][name]
+        nbar = max(1e-4, FACTOR * sc["ref_fp32_vs_fp64_grad_relerr"][tag][name])
+        assert abs(float(p.grad.double().norm()) - n64) <= nbar * n64, name
+        report[name] = entry
+    try:
+        os.makedirs(OUT_DIR, exist_ok=True)
+        with open(os.path.join(OUT_DIR, f"full_parity_{tag}_{prec}.json"), "w") as f:
+            json.dump({"precision": prec, "step": tag, "factor_norm": FACTOR, "factor_elementwise": FACTOR_MAX,
+                       "worst_error_over_bar": worst,
+                       "errors_vs_fp64_oracle": report}, f, indent=1)
+    except OSError:
+        pass
+    return worst
 
 
 # fp32x3: weight gradients on the bf16 pipe with 3-way split operands (same bars as exact fp32)
@@ -60,15 +108,7 @@ def test_full_d_step(full, prec):
     loss.backward()
     for k, v in sc["d_losses64"].items():
         assert abs(float(s.loss_dict[k]) - v) <= 1e-4 * max(1.0, abs(v)), k
-    worst = 0.0
-    for name, p in s.D.named_parameters():
-        e, eref = sample_errors(p.grad, "d", name)
-        bar = max(1e-4, 2 * eref)
-        worst = max(worst, e / bar)
-        assert e <= bar, (name, e, eref)
-        n64 = sc["d_grad_norm64"][name]
-        assert abs(float(p.grad.double().norm()) - n64) <= bar * n64, name
-    print("full D-step", prec, ": worst error / bar =", worst)
+    print("full D-step", prec, ": worst error / bar =", check_grads(s.D, "d", sc, prec))
 
 
 @pytest.mark.parametrize("prec", ["fp32", "fp32x3"])
@@ -81,13 +121,7 @@ def test_full_g_step(full, prec):
     loss.backward()
     for k, v in sc["g_losses64"].items():
         assert abs(float(s.loss_dict[k]) - v) <= 1e-4 * max(1.0, abs(v)), k
-    worst = 0.0
-    for name, p in s.G.named_parameters():
-        e, eref = sample_errors(p.grad, "g", name)
-        bar = max(1e-4, 2 * eref)
-        worst = max(worst, e / bar)
-        assert e <= bar, (name, e, eref)
-    print("full G-step", prec, ": worst error / bar =", worst)
+    print("full G-step", prec, ": worst error / bar =", check_grads(s.G, "g", sc, prec))
 
 
 def test_full_masks_and_eval_forward(full):

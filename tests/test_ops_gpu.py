@@ -261,3 +261,36 @@ def test_weight_packs_match_the_documented_layout(dev, geom):
     assert torch.equal(ops.pack_weight_fwd_x3(wd, g).cpu().view(torch.int16), _split3_ref(fwd).view(torch.int16))
     ax3 = ops.pack_weight_adj_x3(wd, g).cpu()                      # [phase][plane][i][th][tw][o]
     assert torch.equal(ax3.view(torch.int16), _split3_ref(adj).transpose(0, 1).contiguous().view(torch.int16))
+
+
+@pytest.mark.parametrize("ratio", [100.0, 3000.0])
+def test_instnorm_stats_large_mean(dev, ratio):
+    """Channels whose |mean| is `ratio` times their standard deviation (fixed_point_gan.py:28,46 put no bound on
+    it): mean / variance / rstd from the two-pass kernels AND from the statistics fused into the producing
+    convolution's epilogue must still match a float64 evaluation to 1e-5 (the partial sums are taken about a
+    per-thread shift, so sum z^2 does not swallow the variance)."""
+    from fcd_amd import _lib as L, ops
+    torch.manual_seed(7)
+    n, h, w, c = 4, 64, 64, 64
+    sign = torch.where(torch.arange(c) % 2 == 0, 1.0, -1.0)
+    std = 0.5 + torch.rand(c)
+    z = torch.randn(n, h, w, c) * std + ratio * std * sign           # NHWC
+    z64 = z.double()
+    m_ref, v_ref = z64.mean((1, 2)), z64.var((1, 2), unbiased=False)
+    zd = z.to(dev)
+    mean, rstd, varu = ops.instnorm_stats(zd, want_var=True)
+    assert relerr(mean, m_ref) <= 1e-6
+    assert float(((rstd.cpu().double() - (v_ref + 1e-5).rsqrt()) / (v_ref + 1e-5).rsqrt()).abs().max()) <= 1e-5
+    assert float(((varu.cpu().double() - z64.var((1, 2), unbiased=True)) / v_ref).abs().max()) <= 2e-5
+    # fused form: a 1x1 "convolution" with a diagonal weight reproduces z as the conv output
+    for prec in (L.PREC_F32, L.PREC_BF16X3):
+        g = ops.ConvGeom(c, c, 1, 1, 0)
+        d = g.fwd_desc(n, h, w, precision=prec)
+        wt = torch.eye(c).view(c, c, 1, 1).contiguous().to(dev)
+        wp = ops.pack_weight_fwd_x3(wt, g) if ops.wants_split_weights(d) else ops.pack_weight_fwd(wt, g)
+        out, mean_f, rstd_f, varu_f = ops.conv_gather_stats(d, zd, wp, want_var=True)
+        o64 = out.cpu().double()
+        mo, vo = o64.mean((1, 2)), o64.var((1, 2), unbiased=False)
+        assert relerr(out, z) <= 1e-6
+        assert relerr(mean_f, mo) <= 1e-6
+        assert float(((rstd_f.cpu().double() - (vo + 1e-5).rsqrt()) / (vo + 1e-5).rsqrt()).abs().max()) <= 1e-5, prec
