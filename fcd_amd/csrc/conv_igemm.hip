@@ -1081,6 +1081,245 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_dma_kernel(const Wgra
     }
 }
 
+// Weight gradient, FCD_PREC_BF16X3, "split once": the form above splits every fp32 fragment it reads from
+// LDS in registers, and a g / x value is read (and split) by 2 / 4 waves of the workgroup -- 4 split3 per 24
+// MFMAs and wave, which is what bounds it (tools/mfma_bf16_probe.hip: that mix sustains 0.50 of the bf16
+// peak, exactly what the kernel measures).  Here every value is split ONCE: the 512 threads fetch the
+// [32 pixels][BM + 128] fp32 tile global -> registers (buffer loads, one K-tile ahead, out-of-image taps
+// arrive as zeros), split their 24 values and store the three bf16 planes to LDS in the [pixel][channel]
+// order of the tensors; the MFMA operands (K = pixel) come back through ds_read_b64_tr_b16, the hardware's
+// transposed read.  Two stages of planes (144 KiB at BM = 256), one barrier per K-tile.  Chunk c of plane
+// row r sits at c ^ (((r & 3) << 2) | ((r >> 2) & 3)) within its 256-byte segment (plane_off), which makes both
+// the 8-byte stores and the transposed reads conflict-free.  Same products, in the same k slots and the same
+// accumulators, as the kernel above: identical bits.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned plane_off(int row, int chunk, int row_bytes) {
+  // 128-byte rows (a 64-channel plane) hold 8 chunks: rows 4n+2, 4n+3 swap their two 64-byte halves, which
+  // spreads the four rows of a transposed-read block over all 64 banks
+  if (row_bytes == 128) return (unsigned)(row * 128 + 16 * (chunk ^ (((row >> 1) & 1) << 2)));
+  return (unsigned)(row * row_bytes + 256 * (chunk >> 4) + 16 * ((chunk & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3))));
+}
+
+template <int BM, int WM, int WN>
+__global__ __launch_bounds__(512) void conv_wgrad_x3p_kernel(const WgradArgs p, const unsigned gs_bytes,
+                                                             const unsigned xb_bytes) {
+  constexpr int BN = 128, KT = 32, NT = 512;
+  constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
+  static_assert(WM * WN == 8 && TM >= 1 && TN >= 1 && BM % 64 == 0, "shape");
+  constexpr int C4A = BM / 4, RPA = NT / C4A, AL = KT / RPA;     // float4 columns of A, pixel rows per pass, passes
+  constexpr int C4B = BN / 4, RPB = NT / C4B, BL = KT / RPB;
+  constexpr int A_ROW = BM * 2, B_ROW = BN * 2;                  // bytes per plane row
+  constexpr int A_PLANE = KT * A_ROW, B_PLANE = KT * B_ROW;
+  constexpr int STAGE = 3 * (A_PLANE + B_PLANE);
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int ntile = p.tiles_m * p.tiles_n;
+  const int bid = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+  const int ks = bid / ntile, tile = bid - ks * ntile;
+  const int tn = tile % p.tiles_n, tm = tile / p.tiles_n;
+  const int kt0 = ks * p.ktiles_per_split;
+  const int kt1 = min(p.ktiles, kt0 + p.ktiles_per_split);
+  const int nk = kt1 - kt0;
+
+  __amdgpu_buffer_rsrc_t rgs = __builtin_amdgcn_make_buffer_rsrc((void*)p.gs, (short)0, (int)gs_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rxb = __builtin_amdgcn_make_buffer_rsrc((void*)p.xb, (short)0, (int)xb_bytes, 0x00020000);
+
+  // ---- global -> register tile loads
+  const int a_row = tid / C4A, a_c4 = tid % C4A;
+  const int o0 = tm * BM + a_c4 * 4;
+  const bool a_colok = o0 < p.OP;
+  int a_px = kt0 * KT + a_row;                                   // + RPA per pass, + KT per tile
+  const int b_row = tid / C4B, b_c4 = tid % C4B;
+  const int nd = tn * BN + b_c4 * 4;
+  const bool b_colok = nd < p.ND;
+  const int tap = nd / p.IP, ci = nd - tap * p.IP;
+  const int th = tap / p.KW, tw = tap - th * p.KW;
+  const int ghw = p.GH * p.GW;
+  int b_px[BL], b_n[BL], b_a[BL], b_b[BL];
+#pragma unroll
+  for (int i = 0; i < BL; ++i) {
+    b_px[i] = kt0 * KT + b_row + RPB * i;
+    b_n[i] = b_px[i] / ghw;
+    const int rem = b_px[i] - b_n[i] * ghw;
+    b_a[i] = rem / p.GW;
+    b_b[i] = rem - b_a[i] * p.GW;
+  }
+  // one K-tile = KT pixels further = step_n images + step_a rows + step_b columns (branch-free carries)
+  const int step_n = KT / ghw, step_r = KT - step_n * ghw, step_a = step_r / p.GW, step_b = step_r - step_a * p.GW;
+  u32x4 ra[AL], rb[BL];
+  auto load_item = [&](int q_) {
+    if (q_ < AL) {
+      const int px = a_px + RPA * q_;
+      // validity folded into the offset with ALU selects (no branches: the loop body stays one basic block)
+      const unsigned okm = 0u - (unsigned)((int)a_colok & (int)(px < p.P));
+      const unsigned voff = ((unsigned)((px * p.OP + o0) * 4) & okm) | (OOB & ~okm);
+      ra[q_] = __builtin_amdgcn_raw_buffer_load_b128(rgs, (int)voff, 0, 0);
+      if (q_ == AL - 1) a_px += KT;
+    } else {
+      const int i = q_ - AL;
+      const int ih = b_a[i] * p.stride - p.pad + th, iw = b_b[i] * p.stride - p.pad + tw;
+      const unsigned okm = 0u - (unsigned)((int)b_colok & (int)(b_px[i] < p.P) & (int)(ih >= 0) & (int)(ih < p.BH) &
+                                           (int)(iw >= 0) & (int)(iw < p.BW));
+      const unsigned voff = ((unsigned)((((b_n[i] * p.BH + ih) * p.BW + iw) * p.IP + ci) * 4) & okm) | (OOB & ~okm);
+      rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rxb, (int)voff, 0, 0);
+      b_px[i] += KT;
+      int nb = b_b[i] + step_b;
+      const int c1 = nb >= p.GW ? 1 : 0;
+      nb -= c1 ? p.GW : 0;
+      int na = b_a[i] + step_a + c1;
+      const int c2 = na >= p.GH ? 1 : 0;
+      na -= c2 ? p.GH : 0;
+      b_b[i] = nb;
+      b_a[i] = na;
+      b_n[i] += step_n + c2;
+    }
+  };
+  auto load_tile = [&]() {
+#pragma unroll
+    for (int q_ = 0; q_ < AL + BL; ++q_) load_item(q_);
+  };
+  // ---- split + store: this thread's float4 at (row, c4) -> 4 bf16 per plane at the swizzled chunk
+  unsigned a_st[AL], b_st[BL];
+#pragma unroll
+  for (int i = 0; i < AL; ++i) a_st[i] = plane_off(a_row + RPA * i, a_c4 >> 1, A_ROW) + 8 * (a_c4 & 1);
+#pragma unroll
+  for (int i = 0; i < BL; ++i) b_st[i] = 3 * A_PLANE + plane_off(b_row + RPB * i, b_c4 >> 1, B_ROW) + 8 * (b_c4 & 1);
+  auto split_store = [&](const u32x4 v, unsigned char* dst, int plane_bytes) {
+    const float f0 = __uint_as_float(v.x), f1 = __uint_as_float(v.y), f2 = __uint_as_float(v.z), f3 = __uint_as_float(v.w);
+    const unsigned h0 = cvt_pk_bf16(f0, f1), h1 = cvt_pk_bf16(f2, f3);
+    const float r0 = f0 - __uint_as_float(h0 << 16), r1 = f1 - __uint_as_float(h0 & 0xFFFF0000u);
+    const float r2 = f2 - __uint_as_float(h1 << 16), r3 = f3 - __uint_as_float(h1 & 0xFFFF0000u);
+    const unsigned m0 = cvt_pk_bf16(r0, r1), m1 = cvt_pk_bf16(r2, r3);
+    const float s0 = r0 - __uint_as_float(m0 << 16), s1 = r1 - __uint_as_float(m0 & 0xFFFF0000u);
+    const float s2 = r2 - __uint_as_float(m1 << 16), s3 = r3 - __uint_as_float(m1 & 0xFFFF0000u);
+    const unsigned l0 = cvt_pk_bf16(s0, s1), l1 = cvt_pk_bf16(s2, s3);
+    *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(dst + plane_bytes) = make_uint2(m0, m1);
+    *reinterpret_cast<uint2*>(dst + 2 * plane_bytes) = make_uint2(l0, l1);
+  };
+  auto store_item = [&](int q_, unsigned char* base) {
+    if (q_ < AL) split_store(ra[q_], base + a_st[q_], A_PLANE);
+    else split_store(rb[q_ - AL], base + b_st[q_ - AL], B_PLANE);
+  };
+  auto store_tile = [&](int stg) {
+    unsigned char* base = smem + stg * STAGE;
+#pragma unroll
+    for (int q_ = 0; q_ < AL + BL; ++q_) store_item(q_, base);
+  };
+  // ---- transposed fragment reads: lane 4q+pp of 16-lane group g supplies row 8(g>>1) + 4j + q, columns
+  // 16(g&1) + 4pp .. +3 of the 32-column fragment; it receives column 16(g&1) + (lane&15), rows 4j .. 4j+3
+  const int g4 = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+  unsigned a_rd[TM][2], b_rd[TN][2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = 8 * (g4 >> 1) + 4 * j + q;
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+      const int col = wm * WTM + mi * 32 + 16 * (g4 & 1) + 4 * pp;
+      a_rd[mi][j] = plane_off(row, col >> 3, A_ROW) + 8 * ((col >> 2) & 1);
+    }
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) {
+      const int col = wn * WTN + ni * 32 + 16 * (g4 & 1) + 4 * pp;
+      b_rd[ni][j] = 3 * A_PLANE + plane_off(row, col >> 3, B_ROW) + 8 * ((col >> 2) & 1);
+    }
+  }
+  auto frag = [&](const unsigned char* base, unsigned o0_, unsigned o1_) -> bf16x8_t {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + o0_));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + o1_));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+  };
+
+  f32x16 acc[TM][TN], acc2[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = acc2[i][j][r] = 0.f;
+
+  if (nk > 0) {
+    load_tile();
+    store_tile(0);
+    load_tile();                       // tile 1 (zeros past the end of this block's pixel range)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  constexpr int NI = AL + BL, NMF = 12 * TM * TN;      // items and MFMAs per K-tile
+  for (int it = 0; it < nk; ++it) {
+    const unsigned char* cur = smem + (it & 1) * STAGE;
+    unsigned char* nxt = smem + ((it + 1) & 1) * STAGE;
+    // Among the MFMAs of tile it: tile it+1 goes registers -> planes of the other stage (nobody reads it:
+    // the barrier below ended those reads), item by item, and each freed register takes its piece of tile
+    // it+2.  One basic block, no branches: past the end of this block's pixel range the loads fetch zeros
+    // or pixels nobody uses, and the last store lands in a stage that is never read.
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      bf16x8_t ah[TM], am[TM], al[TM], bh[TN], bm2[TN], bl[TN];
+      const unsigned char* ab = cur + s2 * 16 * A_ROW;
+      const unsigned char* bb = cur + s2 * 16 * B_ROW;
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi) {
+        ah[mi] = frag(ab, a_rd[mi][0], a_rd[mi][1]);
+        am[mi] = frag(ab + A_PLANE, a_rd[mi][0], a_rd[mi][1]);
+        al[mi] = frag(ab + 2 * A_PLANE, a_rd[mi][0], a_rd[mi][1]);
+      }
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni) {
+        bh[ni] = frag(bb, b_rd[ni][0], b_rd[ni][1]);
+        bm2[ni] = frag(bb + B_PLANE, b_rd[ni][0], b_rd[ni][1]);
+        bl[ni] = frag(bb + 2 * B_PLANE, b_rd[ni][0], b_rd[ni][1]);
+      }
+#pragma unroll
+      for (int pc = 0; pc < 6; ++pc)
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < TN; ++ni) {
+            const bf16x8_t a = pc == 0 ? al[mi] : (pc == 2 || pc == 3) ? am[mi] : ah[mi];
+            const bf16x8_t b = pc == 1 ? bl[ni] : (pc == 2 || pc == 4) ? bm2[ni] : bh[ni];
+            if (pc < 5) acc2[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc2[mi][ni], 0, 0, 0);
+            else acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[mi][ni], 0, 0, 0);
+            const int g = ((s2 * 6 + pc) * TM + mi) * TN + ni;       // 0 .. NMF-1
+#pragma unroll
+            for (int q_ = 0; q_ < NI; ++q_) {
+              if (q_ * NMF / NI + 1 == g) store_item(q_, nxt);
+              if (q_ * NMF / NI + NMF / (2 * NI) + 1 == g) load_item(q_);
+            }
+          }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] += acc2[i][j][r];
+  // D[row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)][col = lane&31] of sub-tile (mi, ni)
+  float* __restrict__ dst = p.slab + (long)ks * p.O * p.ND;
+  const int lr = lane & 31, lh = lane >> 5;
+#pragma unroll
+  for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) {
+      const int col = tn * BN + wn * WTN + ni * 32 + lr;
+      if (col >= p.ND) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = tm * BM + wm * WTM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (o < p.O) dst[(long)o * p.ND + col] = acc[mi][ni][r];
+      }
+    }
+}
+
 // Weight gradient of a 7x7, stride-1, pad-3 convolution with at most 16 output channels (the
 // generator's last layer: dW[10][64][7][7]) -- the "halo" form.  The generic 16-row kernel above
 // streams the input once per tap (49 times through L2 -> LDS) and needs one DMA instruction per
@@ -1758,6 +1997,17 @@ extern "C" int fcd_conv_wgrad(const FcdWgradDesc* d, const float* gsmall, const 
   } else if (d->O <= 32) {
     a.tiles_m = fcd_cdiv(d->O, 32); a.tiles_n = fcd_cdiv(a.ND, 128);
     rc = launch_wgrad<32, 128, 1, 4>(a, d->precision, st);
+  } else if (d->precision == FCD_PREC_BF16X3 && !getenv("FCD_WGRAD_OLD")) {
+    // split-once kernel (operands split one time per workgroup, transposed LDS reads): same bits as the
+    // in-register-split kernel, 10-20 % faster
+    const int bm = wgrad_bm(d);
+    a.tiles_m = fcd_cdiv(d->O, bm); a.tiles_n = fcd_cdiv(a.ND, 128);
+    dim3 grid(a.tiles_m * a.tiles_n, a.splitk);
+    const unsigned gsb = (unsigned)((size_t)a.P * a.OP * 4), xbb = (unsigned)((size_t)a.N * a.BH * a.BW * a.IP * 4);
+    if (bm == 64) hipLaunchKernelGGL((conv_wgrad_x3p_kernel<64, 2, 4>), grid, dim3(512), 0, st, a, gsb, xbb);
+    else if (bm == 128) hipLaunchKernelGGL((conv_wgrad_x3p_kernel<128, 4, 2>), grid, dim3(512), 0, st, a, gsb, xbb);
+    else hipLaunchKernelGGL((conv_wgrad_x3p_kernel<256, 4, 2>), grid, dim3(512), 0, st, a, gsb, xbb);
+    rc = fcd_check_launch("conv_wgrad");
   } else if (d->O <= 64) {
     a.tiles_m = fcd_cdiv(d->O, 64); a.tiles_n = fcd_cdiv(a.ND, 128);
     rc = launch_wgrad<64, 128, 2, 4>(a, d->precision, st);

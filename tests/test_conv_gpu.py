@@ -274,3 +274,37 @@ def test_conv_7x7_halo_forward(dev, geom, prec):
     out = ops.conv_gather(d, xd, pack_for(d, w.to(dev), g, "fwd"), bias=None if b is None else b.to(dev))
     assert relerr(from_nhwc(out.cpu(), O).double(), ref) <= TOL[prec]
     assert float(out[..., O:].abs().max()) == 0.0 if g.OP > O else True     # padded channels stay zero
+
+
+@pytest.mark.parametrize("shape", [(256, 256, 3, 1, 1, 4, 32, 32), (300, 36, 3, 1, 1, 3, 17, 13), (128, 64, 4, 2, 1, 2, 64, 64),
+                                   (64, 12, 7, 1, 3, 2, 40, 24), (40, 8, 4, 2, 1, 5, 10, 6), (512, 256, 4, 2, 1, 3, 16, 16)])
+def test_wgrad_split_once_equals_in_register_split(dev, shape, monkeypatch):
+    """FCD_PREC_BF16X3 weight gradient: the split-once kernel (operands split one time per workgroup, bf16
+    planes in LDS, transposed reads; conv_wgrad_x3p_kernel) forms the same products in the same k slots and
+    accumulators as the kernel that splits every fragment in registers (FCD_WGRAD_OLD=1): identical bits,
+    and both within 1e-5 of torch's weight gradient."""
+    import torch.nn.functional as F
+    from fcd_amd import ops
+    O, I, k, s, pd, n, h, w = shape
+    g = ops.ConvGeom(O, I, k, s, pd)
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(n, I, h, w, generator=gen)
+    sh, sw = g.small_hw(h, w)
+    gy = torch.randn(n, O, sh, sw, generator=gen)
+    xd = torch.zeros(n, h, w, g.IP)
+    xd[..., :I] = x.permute(0, 2, 3, 1)
+    gd = torch.zeros(n, sh, sw, g.OP)
+    gd[..., :O] = gy.permute(0, 2, 3, 1)
+    xd, gd = xd.to(dev), gd.to(dev)
+    wd = g.wgrad_desc(n, h, w, precision=2)
+    monkeypatch.setenv("FCD_WGRAD_OLD", "1")
+    old = ops.conv_wgrad(wd, gd, xd).clone()
+    monkeypatch.delenv("FCD_WGRAD_OLD")
+    new = ops.conv_wgrad(wd, gd, xd)
+    assert torch.equal(old, new)
+    ref = torch.nn.grad.conv2d_weight(x.double(), (O, I, k, k), gy.double(), stride=s, padding=pd)
+    assert relerr(new, ref) <= 1e-5
+    acc = torch.full_like(new, 0.5)
+    wd2 = g.wgrad_desc(n, h, w, precision=2, accumulate=True)
+    ops.conv_wgrad(wd2, gd, xd, dw=acc)
+    assert relerr(acc - 0.5, ref) <= 1e-5
