@@ -64,6 +64,25 @@ def engine_clock_mhz(dev):
     return None
 
 
+def pmc_traffic(label, symbol):
+    """HBM-side bytes per launch of kernel `symbol` from the rocprofv3 --pmc passes committed under profiles/
+    (tools/prof_traffic.sh -> tools/pmc_traffic.py): FETCH_SIZE x 2 (the gfx950 correction of MI355X_MICROARCH.md:
+    the counter tallies 128-byte requests at 64 bytes) + WRITE_SIZE, both in KB.  The kernel is looked up by the
+    symbol this run really launched (fcd_last_conv_kernel); if the profile does not hold that symbol -- the kernel
+    changed since the profile was taken -- there is no figure, and the reason is reported instead of a stale one."""
+    path = os.path.join(ROOT, "profiles", "r2_traffic.json")
+    try:
+        table = json.load(open(path))[label]
+    except (OSError, KeyError, ValueError) as e:
+        return None, f"no traffic profile for {label!r} in profiles/r2_traffic.json ({type(e).__name__})"
+    hit = table.get(symbol)
+    if hit is None:
+        return None, (f"profiles/r2_traffic.json[{label!r}] has no kernel {symbol!r} (it holds {sorted(table)}): "
+                      "re-run tools/prof_traffic.sh for the current kernels")
+    return int(2 * hit["fetch_size_kb"] * 1024 + hit["write_size_kb"] * 1024), \
+        f"{hit['files'][0]}, {hit['files'][1]}: FETCH_SIZE {hit['fetch_size_kb']:.0f} KB x 2 + WRITE_SIZE {hit['write_size_kb']:.0f} KB"
+
+
 def dominant_kernel_roofline(precision, dev, in_step_us=None, in_step_launches=0, iters=20, symbol=None):
     """The hottest kernel: 3x3 s1 256->256 conv at 32x32 on 32 samples (the G step pairs the reference's
     B=16 generator calls; forward form; dgrad runs the same kernel with flipped taps).  FLOPs per launch
@@ -103,21 +122,18 @@ def dominant_kernel_roofline(precision, dev, in_step_us=None, in_step_launches=0
     flops = 2.0 * n * 256 * 256 * 9 * h * w
     achieved = flops / (ms * 1e-3) / 1e12
     peak = PEAK_TFLOPS[precision]
-    # HBM-side bytes per launch of this same launch (32 samples) from the rocprofv3 PMC passes committed
-    # under profiles/r1_p_resblock_conv_fp32_b32_pmc_*.csv: FETCH_SIZE 34936.5 KB x 2 (gfx950 correction)
-    # + WRITE_SIZE 32768 KB; algorithmic: 33.6 MB input + 2.4 MB weights + 33.6 MB output.
-    traffic = int(2 * 34936.5 * 1024) + 32768 * 1024 if precision in ("fp32", "fp32x3") else None
+    launched = L.load().fcd_last_conv_kernel().decode()
+    traffic, traffic_src = (pmc_traffic("resblock_conv_x3_b32", launched) if precision == "fp32x3"
+                            else (None, "traffic profile taken for the fp32x3 kernel only"))
     extra = {}
     if precision == "fp32x3":
         # six bf16 MFMAs per fp32 product group: the scheme's own ceiling is the bf16 peak / 6
         peak = round(PEAK_TFLOPS["bf16"] / 6, 1)
         extra = {"executed_bf16_tflops": round(6 * achieved, 1), "fp32_mfma_peak": PEAK_TFLOPS["fp32"],
                  "note": "algorithmic fp32 FLOPs; peak = dense bf16 MFMA peak / 6 (six bf16 MFMAs per fp32 product group); "
-                         "the exact-fp32 MFMA pipe peaks at 157.3"}
-        # profiles/r1_r_resblock_conv_x3_b32_tile256_pmc_*.csv (256x128 tile): FETCH_SIZE 30682 KB x 2 +
-        # WRITE_SIZE 33280 KB (the 128x128 tile read 44168 KB x 2: twice as many workgroups re-read the
-        # activation halo rows and the three weight planes)
-        traffic = 2 * 30682 * 1024 + 33280 * 1024
+                         "the exact-fp32 MFMA pipe peaks at 157.3",
+                 "sustained_bf16_mfma_rate": "tools/mfma_bf16_probe.hip: bf16 MFMAs alone, random operands, sustain 0.76 of the "
+                                             "nominal 2.5 PFLOP/s on this card (power), i.e. 317 TFLOP/s in fp32x3 terms"}
     if symbol is not None:
         # all launches of the same kernel symbol in the instrumented steps (what rocprofv3 --stats averages)
         cnt, us, fl = symbol
@@ -127,8 +143,7 @@ def dominant_kernel_roofline(precision, dev, in_step_us=None, in_step_launches=0
             "note": "every launch of this kernel symbol in 2 training steps (all layer shapes; "
                     "launches with fused InstanceNorm statistics include their ~6 us finalize kernel): compare "
                     "with the per-kernel average of profiles/*_kernel_stats.csv"}
-    return {**extra, "bound": "mfma", "kernel": ("conv_gather_dma_kernel<256,128,4,2,2,BF16X3,pre-split weights>" if precision == "fp32x3" else
-                                          "conv_gather_dma_kernel<128,128>") + " 3x3 256->256 @32x32, 32 samples per launch (two paired B=16 calls)",
+    return {**extra, "bound": "mfma", "kernel": launched + " 3x3 256->256 @32x32, 32 samples per launch (two paired B=16 calls)",
             "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
             "us_per_launch": round(ms * 1e3, 2), "launches_timed": in_step_launches,
             "timed": "HIP events around every launch of this kernel in 2 training steps run right after the timed "
@@ -139,8 +154,10 @@ def dominant_kernel_roofline(precision, dev, in_step_us=None, in_step_launches=0
             "frac_at_measured_clock": round(achieved / peak * 2400.0 / sclk, 4) if sclk else None,
             "clock_note": "sysfs pp_dpm_sclk while this kernel runs back to back; the peaks above assume 2400 MHz, "
                           "so frac at the clock the card actually holds is frac * 2400 / engine_clock_mhz_under_kernel",
-            "traffic": traffic,
-            "traffic_unit": "HBM-side bytes per launch (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; profiles/)"}
+            "traffic": traffic, "traffic_source": traffic_src,
+            "algorithmic_bytes": int(2 * n * h * w * 256 * 4 + 256 * 256 * 9 * 6),
+            "traffic_unit": "HBM-side bytes per launch (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, looked up by the launched "
+                            "kernel's symbol); algorithmic: input + output fp32 once + the three bf16 weight planes"}
 
 
 def hbm_kernel_roofline(dev, iters=20):
@@ -161,11 +178,11 @@ def hbm_kernel_roofline(dev, iters=20):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     nbytes = 2.0 * z.numel() * 4
+    traffic, traffic_src = pmc_traffic("in_apply", "in_apply_kernel")
     return {"bound": "hbm", "kernel": "in_apply_kernel (16,128,128,64) fp32", "achieved": round(nbytes / (ms * 1e-3) / 1e9, 1),
             "peak": 8000.0, "unit": "GB/s", "frac": round(nbytes / (ms * 1e-3) / 8e12, 4),
             "us_per_launch": round(ms * 1e3, 2), "mbytes_per_launch": round(nbytes / 1e6, 1),
-            # profiles/r1_q_in_apply_pmc_*.csv: FETCH_SIZE 32854 KB x 2 (gfx950 correction) + WRITE_SIZE 65536 KB
-            "traffic": 2 * 32854 * 1024 + 65536 * 1024}
+            "traffic": traffic, "traffic_source": traffic_src}
 
 
 def inference_rate(solver, dev, iters=5):

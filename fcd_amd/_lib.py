@@ -57,6 +57,7 @@ PROTOTYPES = {
     "fcd_last_error": (C.c_char_p, []),
     "fcd_abi_version": (_I, []),
     "fcd_init": (_I, [_I]),
+    "fcd_last_conv_kernel": (C.c_char_p, []),
     "fcd_conv_workspace_bytes": (_Z, [C.POINTER(ConvDesc)]),
     "fcd_conv_gather": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "fcd_conv_gather_stats_workspace_bytes": (_Z, [C.POINTER(ConvDesc)]),

@@ -1599,8 +1599,20 @@ __global__ __launch_bounds__(256) void pack_adj_x3_kernel(const float* __restric
   }
 }
 
+// Demangled symbol (as rocprofv3 prints it, without namespace and argument list) of the last convolution /
+// weight-gradient kernel this thread launched: lets a benchmark look the launch up in a rocprofv3 counter
+// file by the kernel that really ran (fcd_last_conv_kernel).
+thread_local char g_last_kernel[160] = "";
+void note_kernel(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_last_kernel, sizeof(g_last_kernel), fmt, ap);
+  va_end(ap);
+}
+
 template <int BM, int BN, int WM, int WN>
 int launch_gather(const GatherArgs& a, int precision, hipStream_t st) {
+  note_kernel("conv_gather_dma_kernel<%d, %d, %d, %d, 3, %d, false, false>", BM, BN, WM, WN, precision);
   dim3 grid(a.tiles_m * a.tiles_n, a.nphase * a.splitk);
   const unsigned in_bytes = (unsigned)((size_t)a.N * a.IH * a.IW * a.Cin * 4);
   const unsigned w_bytes = (unsigned)((size_t)a.Cout * a.K * 4);
@@ -1615,6 +1627,7 @@ int launch_gather(const GatherArgs& a, int precision, hipStream_t st) {
 
 template <int BM, int BN, int WM, int WN>
 int launch_wgrad(const WgradArgs& a, int precision, hipStream_t st) {
+  note_kernel("conv_wgrad_dma_kernel<%d, %d, %d, %d, 3, %d, false>", BM, BN, WM, WN, precision);
   dim3 grid(a.tiles_m * a.tiles_n, a.splitk);
   const unsigned gs_bytes = (unsigned)((size_t)a.P * a.OP * 4);
   const unsigned xb_bytes = (unsigned)((size_t)a.N * a.BH * a.BW * a.IP * 4);
@@ -1704,6 +1717,8 @@ void fill_gather_args(const FcdConvDesc* d, GatherArgs& a) {
 
 }  // namespace
 
+extern "C" const char* fcd_last_conv_kernel(void) { return g_last_kernel; }
+
 extern "C" size_t fcd_conv_workspace_bytes(const FcdConvDesc* d) {
   if (!d || d->nphase < 1 || d->Cin <= 0 || d->KH <= 0 || d->KW <= 0) return 0;
   const int sk = resolve_splitk(d);
@@ -1760,6 +1775,7 @@ int run_gather(const FcdConvDesc* d, GatherArgs& a, hipStream_t st) {
   gather_tile(d, bm, bn);
   if (const int rows = halo7_fwd_rows(d, a)) {
     const int nch = fcd_cdiv(d->GW, F7_CW), R = fcd_cdiv(d->GH, rows);
+    note_kernel("conv7_halo_kernel");
     hipLaunchKernelGGL(conv7_halo_kernel, dim3(nch * R, d->N), dim3(64 * H7_WAVES), 0, st, a, rows, nch,
                        (unsigned)((size_t)a.N * a.IH * a.IW * a.Cin * 4));
     return fcd_check_launch("conv7_halo");
@@ -1773,19 +1789,23 @@ int run_gather(const FcdConvDesc* d, GatherArgs& a, hipStream_t st) {
     if (gather_big_tile(d)) {
       a.tiles_m = fcd_cdiv(a.M, 256);
       grid = dim3(a.tiles_m * a.tiles_n, a.nphase * a.splitk);
+      note_kernel(bn == 128 ? "conv_gather_dma_kernel<256, 128, 4, 2, 2, 2, false, true>"
+                            : "conv_gather_dma_kernel<256, 64, 8, 1, 3, 2, false, true>");
       if (bn == 128)
         hipLaunchKernelGGL((conv_gather_dma_kernel<256, 128, 4, 2, 2, FCD_PREC_BF16X3, false, true>), grid, dim3(512), 0, st, a,
                            in_bytes, w_bytes);
       else
         hipLaunchKernelGGL((conv_gather_dma_kernel<256, 64, 8, 1, 3, FCD_PREC_BF16X3, false, true>), grid, dim3(512), 0, st, a,
                            in_bytes, w_bytes);
-    } else if (bn == 128)
+    } else if (bn == 128) {
+      note_kernel("conv_gather_dma_kernel<128, 128, 4, 2, 3, 2, false, true>");
       hipLaunchKernelGGL((conv_gather_dma_kernel<128, 128, 4, 2, 3, FCD_PREC_BF16X3, false, true>), grid, dim3(512), 0, st, a,
                          in_bytes, w_bytes);
-
-    else
+    } else {
+      note_kernel("conv_gather_dma_kernel<128, 64, 4, 2, 3, 2, false, true>");
       hipLaunchKernelGGL((conv_gather_dma_kernel<128, 64, 4, 2, 3, FCD_PREC_BF16X3, false, true>), grid, dim3(512), 0, st, a,
                          in_bytes, w_bytes);
+    }
     rc = fcd_check_launch("conv_gather");
     if (rc) return rc;
     if (a.splitk > 1) {
@@ -1800,6 +1820,7 @@ int run_gather(const FcdConvDesc* d, GatherArgs& a, hipStream_t st) {
   a.tiles_n = fcd_cdiv(d->Cout, bn);
   if (bm == 128 && bn == 16 && d->precision != FCD_PREC_BF16) {
     dim3 grid(a.tiles_m * a.tiles_n, a.nphase * a.splitk);
+    note_kernel("conv_gather_dma_kernel<128, 32, 4, 1, 3, 0, true, false>");
     hipLaunchKernelGGL((conv_gather_dma_kernel<128, 32, 4, 1, 3, FCD_PREC_F32, true>), grid, dim3(256), 0, st, a,
                        (unsigned)((size_t)a.N * a.IH * a.IW * a.Cin * 4), (unsigned)((size_t)a.Cout * a.K * 4));
     rc = fcd_check_launch("conv_gather");
@@ -1985,12 +2006,14 @@ extern "C" int fcd_conv_wgrad(const FcdWgradDesc* d, const float* gsmall, const 
   if (halo) {                                           // exact fp32, input rows loaded once for all 49 taps
     a.splitk = halo;
     dim3 grid(h_nch * h_R, d->N * (d->IP / 16));
+    note_kernel("wgrad7_halo_kernel");
     hipLaunchKernelGGL(wgrad7_halo_kernel, grid, dim3(64 * H7_WAVES), 0, st, a, h_rows, h_R, h_nch,
                        (unsigned)((size_t)a.P * a.OP * 4), (unsigned)((size_t)a.N * a.BH * a.BW * a.IP * 4));
     rc = fcd_check_launch("conv_wgrad");
   } else if (d->O <= 16 && d->precision != FCD_PREC_BF16) {   // exact fp32 16-row kernel, also under BF16X3
     a.tiles_m = 1; a.tiles_n = fcd_cdiv(a.ND, 128);
     dim3 grid(a.tiles_n, a.splitk);
+    note_kernel("conv_wgrad_dma_kernel<32, 128, 1, 4, 3, 0, true>");
     hipLaunchKernelGGL((conv_wgrad_dma_kernel<32, 128, 1, 4, 3, FCD_PREC_F32, true>), grid, dim3(256), 0, st, a,
                        (unsigned)((size_t)a.P * a.OP * 4), (unsigned)((size_t)a.N * a.BH * a.BW * a.IP * 4));
     rc = fcd_check_launch("conv_wgrad");
@@ -2004,6 +2027,7 @@ extern "C" int fcd_conv_wgrad(const FcdWgradDesc* d, const float* gsmall, const 
     a.tiles_m = fcd_cdiv(d->O, bm); a.tiles_n = fcd_cdiv(a.ND, 128);
     dim3 grid(a.tiles_m * a.tiles_n, a.splitk);
     const unsigned gsb = (unsigned)((size_t)a.P * a.OP * 4), xbb = (unsigned)((size_t)a.N * a.BH * a.BW * a.IP * 4);
+    note_kernel("conv_wgrad_x3p_kernel<%d, %d, %d>", bm, bm == 64 ? 2 : 4, bm == 64 ? 4 : 2);
     if (bm == 64) hipLaunchKernelGGL((conv_wgrad_x3p_kernel<64, 2, 4>), grid, dim3(512), 0, st, a, gsb, xbb);
     else if (bm == 128) hipLaunchKernelGGL((conv_wgrad_x3p_kernel<128, 4, 2>), grid, dim3(512), 0, st, a, gsb, xbb);
     else hipLaunchKernelGGL((conv_wgrad_x3p_kernel<256, 4, 2>), grid, dim3(512), 0, st, a, gsb, xbb);

@@ -84,6 +84,11 @@ typedef struct FcdConvDesc {
 } FcdConvDesc;
 
 size_t fcd_conv_workspace_bytes(const FcdConvDesc* d);
+/* Symbol (template instance as rocprofv3 prints it, without namespace and arguments) of the last convolution
+ * or weight-gradient kernel the calling thread launched -- kernel selection is by shape inside the library;
+ * a benchmark uses this to find the launch that really ran in a rocprofv3 counter file.  No reference
+ * counterpart (the reference dispatches to cuDNN). */
+const char* fcd_last_conv_kernel(void);
 int fcd_conv_gather(const FcdConvDesc* d, const float* in, const float* w_packed,
                     const float* bias, const float* mask_src, const float* residual,
                     float* out, void* workspace, size_t workspace_bytes, void* stream);

@@ -1,0 +1,14 @@
+# HBM-side traffic (FETCH_SIZE / WRITE_SIZE, one rocprofv3 --pmc pass each) of the kernels bench.py's roofline
+# objects describe: the dominant convolution, the InstanceNorm apply, the weight gradient.
+set -e
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out
+for w in conv in wgrad; do rm -rf $O/pmc_${w}_f $O/pmc_${w}_w; done
+timeout -s KILL 90 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $O/pmc_conv_f -o r -- python3 $R/tools/conv_once.py 2 0 32 > $O/pmc_conv_f.log 2>&1
+timeout -s KILL 90 rocprofv3 --output-format csv --pmc WRITE_SIZE -d $O/pmc_conv_w -o r -- python3 $R/tools/conv_once.py 2 0 32 > $O/pmc_conv_w.log 2>&1
+timeout -s KILL 90 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $O/pmc_in_f -o r -- python3 $R/tools/in_once.py > $O/pmc_in_f.log 2>&1
+timeout -s KILL 90 rocprofv3 --output-format csv --pmc WRITE_SIZE -d $O/pmc_in_w -o r -- python3 $R/tools/in_once.py > $O/pmc_in_w.log 2>&1
+timeout -s KILL 90 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $O/pmc_wgrad_f -o r -- python3 $R/tools/wgrad_once.py 2 32 > $O/pmc_wgrad_f.log 2>&1
+timeout -s KILL 90 rocprofv3 --output-format csv --pmc WRITE_SIZE -d $O/pmc_wgrad_w -o r -- python3 $R/tools/wgrad_once.py 2 32 > $O/pmc_wgrad_w.log 2>&1
+echo done
