@@ -1507,6 +1507,171 @@ __global__ __launch_bounds__(64 * H7_WAVES) void conv7_halo_kernel(const GatherA
   }
 }
 
+// 7x7, stride-1, pad-3 convolution from 12 physical channels to 64 (the generator's first layer, 11 -> 64,
+// and the last layer's data gradient, 10 -> 64), FCD_PREC_BF16X3, "halo" form.  The generic gather kernel pulls
+// every input pixel through L2 -> LDS once per tap (49 times: 1.2 GB per 32-sample launch against 25 MB of
+// input) and splits activations and weights in registers.  Here a workgroup owns (image, 64-column strip,
+// row range): every input row is fetched ONCE (global -> registers), split once into three bf16 planes and
+// kept in an 8-slot LDS ring [slot][plane][72 pixels][12 channels].  With 12 channels per pixel the 7 taps of a
+// tap row are 84 consecutive values of the ring row, so the K axis of tap row th is one contiguous run
+// (padded to 96 = 6 k16-steps with zero weights): each of the 7 waves owns one tap row, holds its 96 x 64
+// weights pre-split in registers for the whole kernel (144 VGPRs) and reads its A fragments straight from
+// the planes (no split in the loop).  The 7 partial [32 pixels][64 channels] tiles of a chunk are summed through
+// LDS in a fixed order (wave 0 .. 6); the InstanceNorm statistics of the output ride in that pass.
+constexpr int C12_CW = 64;            // output columns per workgroup
+constexpr int C12_XW = 72;            // pixels per ring row: 64 + 6 halo, + 2 so that k = 84..95 of the last pixel stays inside
+constexpr int C12_WAVES = 7;
+constexpr int C12_ROWB = C12_XW * 12 * 2;                 // bytes per plane row
+constexpr int C12_SLOT = 3 * C12_ROWB;
+__global__ __launch_bounds__(64 * C12_WAVES) void conv7_c12_halo_x3_kernel(const GatherArgs p, const int rows, const int nch,
+                                                                          const unsigned in_bytes) {
+  __shared__ __attribute__((aligned(16))) unsigned char Xp[8 * C12_SLOT];
+  __shared__ __attribute__((aligned(16))) float Rs[2 * C12_WAVES * 32 * 64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ch = blockIdx.x % nch, rr = blockIdx.x / nch, n = blockIdx.y;
+  const int x0 = ch * C12_CW, y0 = rr * rows, y1 = min(p.OH, y0 + rows);
+  __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, (short)0, (int)in_bytes, 0x00020000);
+
+  // ---- input rows: thread t < 216 owns float4 t of the 72-pixel row (pixel t / 3, channels 4 (t % 3) ..)
+  const bool loader = tid < C12_XW * 3;
+  const int lpx = tid / 3, lc4 = tid - lpx * 3;
+  const int gx = x0 - 3 + lpx;
+  auto load_row = [&](int yy) -> u32x4 {
+    const unsigned okm = 0u - (unsigned)((int)loader & (int)(yy >= 0) & (int)(yy < p.IH) & (int)(gx >= 0) & (int)(gx < p.IW));
+    const unsigned voff = ((unsigned)((((n * p.IH + yy) * p.IW + gx) * 12 + lc4 * 4) * 4) & okm) | (OOB & ~okm);
+    return __builtin_amdgcn_raw_buffer_load_b128(rin, (int)voff, 0, 0);
+  };
+  auto store_row = [&](const u32x4 v, int yy) {
+    if (!loader) return;
+    unsigned char* dst = Xp + ((yy + 16) & 7) * C12_SLOT + lpx * 24 + lc4 * 8;
+    const float f0 = __uint_as_float(v.x), f1 = __uint_as_float(v.y), f2 = __uint_as_float(v.z), f3 = __uint_as_float(v.w);
+    const unsigned h0 = cvt_pk_bf16(f0, f1), h1 = cvt_pk_bf16(f2, f3);
+    const float r0 = f0 - __uint_as_float(h0 << 16), r1 = f1 - __uint_as_float(h0 & 0xFFFF0000u);
+    const float r2 = f2 - __uint_as_float(h1 << 16), r3 = f3 - __uint_as_float(h1 & 0xFFFF0000u);
+    const unsigned m0 = cvt_pk_bf16(r0, r1), m1 = cvt_pk_bf16(r2, r3);
+    const float s0 = r0 - __uint_as_float(m0 << 16), s1 = r1 - __uint_as_float(m0 & 0xFFFF0000u);
+    const float s2 = r2 - __uint_as_float(m1 << 16), s3 = r3 - __uint_as_float(m1 & 0xFFFF0000u);
+    *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(dst + C12_ROWB) = make_uint2(m0, m1);
+    *reinterpret_cast<uint2*>(dst + 2 * C12_ROWB) = make_uint2(cvt_pk_bf16(s0, s1), cvt_pk_bf16(s2, s3));
+  };
+  for (int yy = y0 - 3; yy <= y0 + 3; ++yy) store_row(load_row(yy), yy);
+
+  // ---- this wave's weights: tap row th = wave, k = tw * 12 + ci (84 real values, zeros up to 96);
+  // B fragment of k16-step ks, n-tile ni: lane (co = 32 ni + (lane & 31), k = 16 ks + 8 (lane >> 5) .. +7)
+  const int lr = lane & 31, lh = lane >> 5;
+  bf16x8_t wh[6][2], wm[6][2], wl[6][2];
+#pragma unroll
+  for (int ks = 0; ks < 6; ++ks)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int co = 32 * ni + lr, k0 = 16 * ks + 8 * lh;
+      const float* src = p.w + (long)co * p.K + wave * 84 + k0;
+      f32x8 f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = (co < p.Cout && k0 + j < 84) ? src[j] : 0.f;
+      split3(f, wh[ks][ni], wm[ks][ni], wl[ks][ni]);
+    }
+  __syncthreads();
+
+  // per-thread slice of the sum phase: float4 idx = tid (+ 448): pixel idx / 16, channels 4 (idx % 16) .. +3
+  const int c4 = tid & 15;
+  float ssum[4] = {0.f, 0.f, 0.f, 0.f}, qsum[4] = {0.f, 0.f, 0.f, 0.f}, ssh[4] = {0.f, 0.f, 0.f, 0.f};
+  int scnt = 0;
+
+  for (int y = y0; y < y1; ++y) {
+    const u32x4 nextrow = load_row(y + 4);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const unsigned char* Arow = Xp + ((y + wave - 3 + 16) & 7) * C12_SLOT + (32 * c + lr) * 24 + 16 * lh;
+      f32x16 acc[2], acc2[2];
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ni][r] = acc2[ni][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 6; ++ks) {
+        bf16x8_t a[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          const uint2 lo = *reinterpret_cast<const uint2*>(Arow + pl * C12_ROWB + 32 * ks);
+          const uint2 hi = *reinterpret_cast<const uint2*>(Arow + pl * C12_ROWB + 32 * ks + 8);
+          const u32x4 v = {lo.x, lo.y, hi.x, hi.y};
+          a[pl] = __builtin_bit_cast(bf16x8_t, v);
+        }
+#pragma unroll
+        for (int pc = 0; pc < 6; ++pc)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) {
+            const bf16x8_t av = pc == 0 ? a[2] : (pc == 2 || pc == 3) ? a[1] : a[0];
+            const bf16x8_t bv = pc == 1 ? wl[ks][ni] : (pc == 2 || pc == 4) ? wm[ks][ni] : wh[ks][ni];
+            if (pc < 5) acc2[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc2[ni], 0, 0, 0);
+            else acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[ni], 0, 0, 0);
+          }
+      }
+      // D[pixel = (r&3) + 8 (r>>2) + 4 lh][co = 32 ni + lr] -> Rs[parity c][wave][pixel][co]
+      float* R = Rs + (c * C12_WAVES + wave) * (32 * 64);
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) R[((r & 3) + 8 * (r >> 2) + 4 * lh) * 64 + 32 * ni + lr] = acc[ni][r] + acc2[ni][r];
+      __syncthreads();
+      if (c == 0) store_row(nextrow, y + 4);     // every wave is past row y - 1: slot (y + 4) & 7 = (y - 4) & 7 is free
+      // fixed-order sum of the 7 tap rows, store, statistics
+      const float* R0 = Rs + c * C12_WAVES * (32 * 64);
+      for (int idx = tid; idx < 32 * 16; idx += 64 * C12_WAVES) {
+        const int px = idx >> 4;
+        float4 v = *reinterpret_cast<const float4*>(R0 + idx * 4);
+#pragma unroll
+        for (int w7 = 1; w7 < C12_WAVES; ++w7) {
+          const float4 t = *reinterpret_cast<const float4*>(R0 + w7 * (32 * 64) + idx * 4);
+          v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+        const int ox = x0 + 32 * c + px;
+        if (ox < p.OW) {
+          *reinterpret_cast<float4*>(p.out + (((long)n * p.OH + y) * p.OW + ox) * 64 + 4 * c4) = v;
+          if (p.stats) {
+            const float vv[4] = {v.x, v.y, v.z, v.w};
+            if (scnt == 0) { ssh[0] = v.x; ssh[1] = v.y; ssh[2] = v.z; ssh[3] = v.w; }
+            ++scnt;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float dv = vv[e] - ssh[e];
+              ssum[e] += dv;
+              qsum[e] += dv * dv;
+            }
+          }
+        }
+      }
+    }
+  }
+  if (p.stats) {
+    // 28 threads share a channel group (tid & 15): partials as doubles through LDS, summed in thread order
+    __syncthreads();
+    double* D = reinterpret_cast<double*>(Rs);          // [448][4][2]
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const double shd = (double)ssh[e], cn = (double)scnt;
+      D[(tid * 4 + e) * 2 + 0] = (double)ssum[e] + cn * shd;
+      D[(tid * 4 + e) * 2 + 1] = (double)qsum[e] + 2.0 * shd * (double)ssum[e] + cn * shd * shd;
+    }
+    __syncthreads();
+    if (tid < 64) {
+      const int g = tid >> 2, e = tid & 3;             // channel tid = 4 g + e
+      double s = 0.0, q = 0.0;
+      for (int t = g; t < 64 * C12_WAVES; t += 16) {
+        s += D[(t * 4 + e) * 2 + 0];
+        q += D[(t * 4 + e) * 2 + 1];
+      }
+      const long chunk = (long)n * p.stats_cpp + blockIdx.x;
+      double* d2 = p.stats + (chunk * p.CoutP + tid) * 2;
+      d2[0] = s;
+      d2[1] = q;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void pack_fwd_kernel(const float* __restrict__ w, float* __restrict__ out,
                                                        int O, int I, int IP, int taps) {
   const long total = (long)O * taps * IP;
@@ -1770,9 +1935,35 @@ int halo7_fwd_rows(const FcdConvDesc* d, const GatherArgs& a) {
   return fcd_cdiv(d->GH, (int)rr);
 }
 
+// The halo form of the 7x7, 12 -> 64 channel convolution under FCD_PREC_BF16X3 (conv7_c12_halo_x3_kernel):
+// rows per workgroup (0 = not applicable); *nchunks = workgroups per image (the statistics chunks).
+int halo12_rows(const FcdConvDesc* d, int* nchunks) {
+  if (getenv("FCD_NO_HALO12")) return 0;
+  if (d->precision != FCD_PREC_BF16X3 || d->KH != 7 || d->KW != 7 || d->nphase != 1 || d->istride != 1 || d->ostride != 1) return 0;
+  if (d->pad_h[0] != 3 || d->pad_w[0] != 3 || d->Cin != 12 || d->Cout != 64 || d->CoutP != 64) return 0;
+  if (d->GH != d->IH || d->GW != d->IW || d->OH != d->GH || d->OW != d->GW || d->ooff_h[0] || d->ooff_w[0]) return 0;
+  if (d->act_slope != 1.f || (d->splitk > 1)) return 0;
+  // about one workgroup per CU; a shorter row range only re-loads its 6 halo rows more often
+  const int nch = fcd_cdiv(d->GW, C12_CW);
+  const long base = (long)d->N * nch;
+  long rr = (256 + base / 2) / base;
+  if (rr > d->GH / 8) rr = d->GH / 8;
+  if (rr < 1) rr = 1;
+  const int rows = fcd_cdiv(d->GH, (int)rr);
+  if (nchunks) *nchunks = nch * fcd_cdiv(d->GH, rows);
+  return rows;
+}
+
 int run_gather(const FcdConvDesc* d, GatherArgs& a, hipStream_t st) {
   int bm, bn, rc;
   gather_tile(d, bm, bn);
+  if (const int rows = (a.bias || a.mask || a.res) ? 0 : halo12_rows(d, nullptr)) {
+    const int nch = fcd_cdiv(d->GW, C12_CW), R = fcd_cdiv(d->GH, rows);
+    note_kernel("conv7_c12_halo_x3_kernel");
+    hipLaunchKernelGGL(conv7_c12_halo_x3_kernel, dim3(nch * R, d->N), dim3(64 * C12_WAVES), 0, st, a, rows, nch,
+                       (unsigned)((size_t)a.N * a.IH * a.IW * a.Cin * 4));
+    return fcd_check_launch("conv7_c12_halo_x3");
+  }
   if (const int rows = halo7_fwd_rows(d, a)) {
     const int nch = fcd_cdiv(d->GW, F7_CW), R = fcd_cdiv(d->GH, rows);
     note_kernel("conv7_halo_kernel");
@@ -1843,6 +2034,8 @@ int run_gather(const FcdConvDesc* d, GatherArgs& a, hipStream_t st) {
 // chunks per image when the statistics can ride in the epilogue, else 0
 int fused_stats_chunks(const FcdConvDesc* d) {
   int bm, bn;
+  int hchunks = 0;
+  if (halo12_rows(d, &hchunks)) return hchunks;      // the halo kernel's sum pass carries the statistics
   gather_tile(d, bm, bn);
   if (bn == 16 || resolve_splitk(d) != 1) return 0;
   // rows per wave: the pre-split kernels run 4 x 2 waves on 128 rows, 4 x 2 or 8 x 1 on 256

@@ -308,3 +308,55 @@ def test_wgrad_split_once_equals_in_register_split(dev, shape, monkeypatch):
     wd2 = g.wgrad_desc(n, h, w, precision=2, accumulate=True)
     ops.conv_wgrad(wd2, gd, xd, dw=acc)
     assert relerr(acc - 0.5, ref) <= 1e-5
+
+
+@pytest.mark.parametrize("shape", [(2, 40, 24, 11), (1, 9, 130, 10), (3, 64, 64, 11), (4, 128, 128, 11)])
+def test_conv7_c12_halo_x3(dev, shape, monkeypatch):
+    """The 7x7, 12 -> 64 channel convolution of the generator's first layer (fixed_point_gan.py:45) and of the last
+    layer's data gradient under FCD_PREC_BF16X3: the LDS-halo kernel (input rows loaded and split once, one wave
+    per tap row, fixed-order sum of the 7 partial tiles) against torch's conv2d in float64 and against the generic
+    gather kernel (FCD_NO_HALO12=1), with and without the fused InstanceNorm statistics, ragged widths and heights,
+    and as the adjoint (data gradient) of the 64 -> 10 convolution."""
+    from fcd_amd import _lib as L, ops
+    n, h, w, cin = shape
+    g = ops.ConvGeom(64, cin, 7, 1, 3)
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(n, cin, h, w, generator=gen)
+    wt = torch.randn(64, cin, 7, 7, generator=gen) / 23.0
+    xd = torch.zeros(n, h, w, g.IP)
+    xd[..., :cin] = x.permute(0, 2, 3, 1)
+    xd = xd.to(dev)
+    d = g.fwd_desc(n, h, w, precision=2)
+    wp = ops.pack_weight_fwd(wt.to(dev), g)
+    ref = F.conv2d(x.double(), wt.double(), padding=3).permute(0, 2, 3, 1)
+    out, mean, rstd, varu = ops.conv_gather_stats(d, xd, wp, want_var=True)
+    assert L.load().fcd_last_conv_kernel() == b"conv7_c12_halo_x3_kernel"
+    assert relerr(out, ref) <= 1e-6
+    m_ref, v_ref = ref.mean((1, 2)), ref.var((1, 2), unbiased=False)
+    assert relerr(mean, m_ref) <= 1e-5
+    assert float(((rstd.cpu().double() - (v_ref + 1e-5).rsqrt()) / (v_ref + 1e-5).rsqrt()).abs().max()) <= 1e-5
+    assert relerr(varu, ref.var((1, 2), unbiased=True)) <= 1e-5
+    plain = ops.conv_gather(d, xd, wp)
+    assert torch.equal(plain, out)                      # the statistics do not change the convolution
+    monkeypatch.setenv("FCD_NO_HALO12", "1")
+    generic = ops.conv_gather(d, xd, wp)
+    assert L.load().fcd_last_conv_kernel() != b"conv7_c12_halo_x3_kernel"
+    monkeypatch.delenv("FCD_NO_HALO12")
+    assert relerr(out, generic) <= 1e-6
+    # epilogue operands the halo kernel does not implement fall back to the generic kernel
+    bias = torch.randn(64, generator=gen).to(dev)
+    withb = ops.conv_gather(d, xd, wp, bias=bias)
+    assert L.load().fcd_last_conv_kernel() != b"conv7_c12_halo_x3_kernel"
+    assert relerr(withb, ref + bias.cpu().double()) <= 1e-6
+    # adjoint use: data gradient of Conv2d(64 -> cout, 7x7) with cout = 10 (12 physical channels)
+    cout = 10
+    g2 = ops.ConvGeom(cout, 64, 7, 1, 3)
+    w2 = torch.randn(cout, 64, 7, 7, generator=gen) / 56.0
+    gy = torch.randn(n, cout, h, w, generator=gen)
+    gyd = torch.zeros(n, h, w, g2.OP)
+    gyd[..., :cout] = gy.permute(0, 2, 3, 1)
+    d2 = g2.adj_desc(n, h, w, precision=2)
+    gx = ops.conv_gather(d2, gyd.to(dev), ops.pack_weight_adj(w2.to(dev), g2))
+    assert L.load().fcd_last_conv_kernel() == b"conv7_c12_halo_x3_kernel"
+    gx_ref = torch.nn.grad.conv2d_input((n, 64, h, w), w2.double(), gy.double(), padding=3).permute(0, 2, 3, 1)
+    assert relerr(gx, gx_ref) <= 1e-6
