@@ -1520,11 +1520,11 @@ __global__ __launch_bounds__(64 * H7_WAVES) void conv7_halo_kernel(const GatherA
 // LDS in a fixed order (wave 0 .. 6); the InstanceNorm statistics of the output ride in that pass.
 constexpr int C12_CW = 64;            // output columns per workgroup
 constexpr int C12_XW = 72;            // pixels per ring row: 64 + 6 halo, + 2 so that k = 84..95 of the last pixel stays inside
-constexpr int C12_WAVES = 7;
+constexpr int C12_WAVES = 7;          // MFMA waves (one per tap row); an eighth wave loads, splits and sums
 constexpr int C12_ROWB = C12_XW * 12 * 2;                 // bytes per plane row
 constexpr int C12_SLOT = 3 * C12_ROWB;
-__global__ __launch_bounds__(64 * C12_WAVES) void conv7_c12_halo_x3_kernel(const GatherArgs p, const int rows, const int nch,
-                                                                          const unsigned in_bytes) {
+__global__ __launch_bounds__(64 * (C12_WAVES + 1)) void conv7_c12_halo_x3_kernel(const GatherArgs p, const int rows, const int nch,
+                                                                                const unsigned in_bytes) {
   __shared__ __attribute__((aligned(16))) unsigned char Xp[8 * C12_SLOT];
   __shared__ __attribute__((aligned(16))) float Rs[2 * C12_WAVES * 32 * 64];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1533,17 +1533,16 @@ __global__ __launch_bounds__(64 * C12_WAVES) void conv7_c12_halo_x3_kernel(const
   const int x0 = ch * C12_CW, y0 = rr * rows, y1 = min(p.OH, y0 + rows);
   __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, (short)0, (int)in_bytes, 0x00020000);
 
-  // ---- input rows: thread t < 216 owns float4 t of the 72-pixel row (pixel t / 3, channels 4 (t % 3) ..)
-  const bool loader = tid < C12_XW * 3;
-  const int lpx = tid / 3, lc4 = tid - lpx * 3;
-  const int gx = x0 - 3 + lpx;
-  auto load_row = [&](int yy) -> u32x4 {
-    const unsigned okm = 0u - (unsigned)((int)loader & (int)(yy >= 0) & (int)(yy < p.IH) & (int)(gx >= 0) & (int)(gx < p.IW));
+  // ---- input rows: float4 f of the 72-pixel row = pixel f / 3, channels 4 (f % 3) ..; 216 per row
+  auto load_f4 = [&](int f, int yy) -> u32x4 {
+    const int lpx = f / 3, lc4 = f - lpx * 3, gx = x0 - 3 + lpx;
+    const unsigned okm = 0u - (unsigned)((int)(f < C12_XW * 3) & (int)(yy >= 0) & (int)(yy < p.IH) & (int)(gx >= 0) & (int)(gx < p.IW));
     const unsigned voff = ((unsigned)((((n * p.IH + yy) * p.IW + gx) * 12 + lc4 * 4) * 4) & okm) | (OOB & ~okm);
     return __builtin_amdgcn_raw_buffer_load_b128(rin, (int)voff, 0, 0);
   };
-  auto store_row = [&](const u32x4 v, int yy) {
-    if (!loader) return;
+  auto store_f4 = [&](const u32x4 v, int f, int yy) {
+    if (f >= C12_XW * 3) return;
+    const int lpx = f / 3, lc4 = f - lpx * 3;
     unsigned char* dst = Xp + ((yy + 16) & 7) * C12_SLOT + lpx * 24 + lc4 * 8;
     const float f0 = __uint_as_float(v.x), f1 = __uint_as_float(v.y), f2 = __uint_as_float(v.z), f3 = __uint_as_float(v.w);
     const unsigned h0 = cvt_pk_bf16(f0, f1), h1 = cvt_pk_bf16(f2, f3);
@@ -1556,9 +1555,77 @@ __global__ __launch_bounds__(64 * C12_WAVES) void conv7_c12_halo_x3_kernel(const
     *reinterpret_cast<uint2*>(dst + C12_ROWB) = make_uint2(m0, m1);
     *reinterpret_cast<uint2*>(dst + 2 * C12_ROWB) = make_uint2(cvt_pk_bf16(s0, s1), cvt_pk_bf16(s2, s3));
   };
-  for (int yy = y0 - 3; yy <= y0 + 3; ++yy) store_row(load_row(yy), yy);
+  // prologue: rows y0-3 .. y0+3, all 512 threads
+  for (int yy = y0 - 3; yy <= y0 + 3; ++yy) store_f4(load_f4(tid, yy), tid, yy);
 
-  // ---- this wave's weights: tap row th = wave, k = tw * 12 + ci (84 real values, zeros up to 96);
+  if (wave == C12_WAVES) {
+    // ================= helper wave: next input row (load, split, store) and the sum of the 7 partial tiles
+    __syncthreads();
+    const int c4 = lane & 15;              // this lane's channels 4 c4 .. +3 in every float4 it sums
+    float ssum[4] = {0.f, 0.f, 0.f, 0.f}, qsum[4] = {0.f, 0.f, 0.f, 0.f}, ssh[4] = {0.f, 0.f, 0.f, 0.f};
+    int scnt = 0;
+    for (int y = y0; y < y1; ++y) {
+      u32x4 nr[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) nr[j] = load_f4(lane + 64 * j, y + 4);
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        __syncthreads();                   // partial tiles of chunk (y, c) are complete
+        if (c == 0) {
+          // every wave is past row y - 1: slot (y + 4) & 7 = (y - 4) & 7 is free; visible after the next barrier
+#pragma unroll
+          for (int j = 0; j < 4; ++j) store_f4(nr[j], lane + 64 * j, y + 4);
+        }
+        const float* R0 = Rs + c * C12_WAVES * (32 * 64);
+#pragma unroll 2
+        for (int j = 0; j < 8; ++j) {
+          const int idx = lane + 64 * j, px = idx >> 4;
+          float4 v = *reinterpret_cast<const float4*>(R0 + idx * 4);
+#pragma unroll
+          for (int w7 = 1; w7 < C12_WAVES; ++w7) {
+            const float4 t = *reinterpret_cast<const float4*>(R0 + w7 * (32 * 64) + idx * 4);
+            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+          }
+          const int ox = x0 + 32 * c + px;
+          if (ox < p.OW) {
+            *reinterpret_cast<float4*>(p.out + (((long)n * p.OH + y) * p.OW + ox) * 64 + 4 * c4) = v;
+            if (p.stats) {
+              const float vv[4] = {v.x, v.y, v.z, v.w};
+              if (scnt == 0) { ssh[0] = v.x; ssh[1] = v.y; ssh[2] = v.z; ssh[3] = v.w; }
+              ++scnt;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float dv = vv[e] - ssh[e];
+                ssum[e] += dv;
+                qsum[e] += dv * dv;
+              }
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();                       // (pairs with the MFMA waves' final barrier)
+    if (p.stats) {
+      // lanes l, l+16, l+32, l+48 share a channel group: doubles, summed in lane order
+      const long chunk = (long)n * p.stats_cpp + blockIdx.x;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const double shd = (double)ssh[e], cn = (double)scnt;
+        double s = (double)ssum[e] + cn * shd;
+        double q = (double)qsum[e] + 2.0 * shd * (double)ssum[e] + cn * shd * shd;
+        const double s1 = __shfl(s, c4 + 16), s2 = __shfl(s, c4 + 32), s3 = __shfl(s, c4 + 48);
+        const double q1 = __shfl(q, c4 + 16), q2 = __shfl(q, c4 + 32), q3 = __shfl(q, c4 + 48);
+        if (lane < 16) {
+          double* d2 = p.stats + (chunk * p.CoutP + 4 * c4 + e) * 2;
+          d2[0] = ((s + s1) + s2) + s3;
+          d2[1] = ((q + q1) + q2) + q3;
+        }
+      }
+    }
+    return;
+  }
+
+  // ================= MFMA waves: tap row th = wave.  Weights: k = tw * 12 + ci (84 real values, zeros up to 96);
   // B fragment of k16-step ks, n-tile ni: lane (co = 32 ni + (lane & 31), k = 16 ks + 8 (lane >> 5) .. +7)
   const int lr = lane & 31, lh = lane >> 5;
   bf16x8_t wh[6][2], wm[6][2], wl[6][2];
@@ -1575,13 +1642,7 @@ __global__ __launch_bounds__(64 * C12_WAVES) void conv7_c12_halo_x3_kernel(const
     }
   __syncthreads();
 
-  // per-thread slice of the sum phase: float4 idx = tid (+ 448): pixel idx / 16, channels 4 (idx % 16) .. +3
-  const int c4 = tid & 15;
-  float ssum[4] = {0.f, 0.f, 0.f, 0.f}, qsum[4] = {0.f, 0.f, 0.f, 0.f}, ssh[4] = {0.f, 0.f, 0.f, 0.f};
-  int scnt = 0;
-
   for (int y = y0; y < y1; ++y) {
-    const u32x4 nextrow = load_row(y + 4);
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       const unsigned char* Arow = Xp + ((y + wave - 3 + 16) & 7) * C12_SLOT + (32 * c + lr) * 24 + 16 * lh;
@@ -1610,66 +1671,17 @@ __global__ __launch_bounds__(64 * C12_WAVES) void conv7_c12_halo_x3_kernel(const
             else acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[ni], 0, 0, 0);
           }
       }
-      // D[pixel = (r&3) + 8 (r>>2) + 4 lh][co = 32 ni + lr] -> Rs[parity c][wave][pixel][co]
+      // D[pixel = (r&3) + 8 (r>>2) + 4 lh][co = 32 ni + lr] -> Rs[parity c][wave][pixel][co].  This parity was last
+      // read by the helper for chunk (y-1, c); it reached the barrier of chunk (y-1, c^1) ... (y, c^1) only after that.
       float* R = Rs + (c * C12_WAVES + wave) * (32 * 64);
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
         for (int r = 0; r < 16; ++r) R[((r & 3) + 8 * (r >> 2) + 4 * lh) * 64 + 32 * ni + lr] = acc[ni][r] + acc2[ni][r];
       __syncthreads();
-      if (c == 0) store_row(nextrow, y + 4);     // every wave is past row y - 1: slot (y + 4) & 7 = (y - 4) & 7 is free
-      // fixed-order sum of the 7 tap rows, store, statistics
-      const float* R0 = Rs + c * C12_WAVES * (32 * 64);
-      for (int idx = tid; idx < 32 * 16; idx += 64 * C12_WAVES) {
-        const int px = idx >> 4;
-        float4 v = *reinterpret_cast<const float4*>(R0 + idx * 4);
-#pragma unroll
-        for (int w7 = 1; w7 < C12_WAVES; ++w7) {
-          const float4 t = *reinterpret_cast<const float4*>(R0 + w7 * (32 * 64) + idx * 4);
-          v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
-        }
-        const int ox = x0 + 32 * c + px;
-        if (ox < p.OW) {
-          *reinterpret_cast<float4*>(p.out + (((long)n * p.OH + y) * p.OW + ox) * 64 + 4 * c4) = v;
-          if (p.stats) {
-            const float vv[4] = {v.x, v.y, v.z, v.w};
-            if (scnt == 0) { ssh[0] = v.x; ssh[1] = v.y; ssh[2] = v.z; ssh[3] = v.w; }
-            ++scnt;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float dv = vv[e] - ssh[e];
-              ssum[e] += dv;
-              qsum[e] += dv * dv;
-            }
-          }
-        }
-      }
     }
   }
-  if (p.stats) {
-    // 28 threads share a channel group (tid & 15): partials as doubles through LDS, summed in thread order
-    __syncthreads();
-    double* D = reinterpret_cast<double*>(Rs);          // [448][4][2]
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const double shd = (double)ssh[e], cn = (double)scnt;
-      D[(tid * 4 + e) * 2 + 0] = (double)ssum[e] + cn * shd;
-      D[(tid * 4 + e) * 2 + 1] = (double)qsum[e] + 2.0 * shd * (double)ssum[e] + cn * shd * shd;
-    }
-    __syncthreads();
-    if (tid < 64) {
-      const int g = tid >> 2, e = tid & 3;             // channel tid = 4 g + e
-      double s = 0.0, q = 0.0;
-      for (int t = g; t < 64 * C12_WAVES; t += 16) {
-        s += D[(t * 4 + e) * 2 + 0];
-        q += D[(t * 4 + e) * 2 + 1];
-      }
-      const long chunk = (long)n * p.stats_cpp + blockIdx.x;
-      double* d2 = p.stats + (chunk * p.CoutP + tid) * 2;
-      d2[0] = s;
-      d2[1] = q;
-    }
-  }
+  __syncthreads();
 }
 
 __global__ __launch_bounds__(256) void pack_fwd_kernel(const float* __restrict__ w, float* __restrict__ out,
@@ -1960,7 +1972,7 @@ int run_gather(const FcdConvDesc* d, GatherArgs& a, hipStream_t st) {
   if (const int rows = (a.bias || a.mask || a.res) ? 0 : halo12_rows(d, nullptr)) {
     const int nch = fcd_cdiv(d->GW, C12_CW), R = fcd_cdiv(d->GH, rows);
     note_kernel("conv7_c12_halo_x3_kernel");
-    hipLaunchKernelGGL(conv7_c12_halo_x3_kernel, dim3(nch * R, d->N), dim3(64 * C12_WAVES), 0, st, a, rows, nch,
+    hipLaunchKernelGGL(conv7_c12_halo_x3_kernel, dim3(nch * R, d->N), dim3(64 * (C12_WAVES + 1)), 0, st, a, rows, nch,
                        (unsigned)((size_t)a.N * a.IH * a.IW * a.Cin * 4));
     return fcd_check_launch("conv7_c12_halo_x3");
   }
