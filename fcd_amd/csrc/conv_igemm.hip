@@ -204,6 +204,14 @@ __device__ __forceinline__ void dma16(const i32x4 rsrc, const unsigned voff, con
       : "memory");
 }
 
+// Operands may exceed 2 GiB: every workgroup addresses a window of the tensor that starts at a wave-uniform
+// byte offset `start` (its first image / pixel row) and keeps 32-bit lane offsets inside it.  The window is
+// cut at 2 GiB so that OOB stays out of range; the host checks that a workgroup's span fits.
+__device__ __forceinline__ unsigned window_bytes(const size_t total, const size_t start) {
+  const size_t left = total - start;
+  return left < (size_t)OOB ? (unsigned)left : OOB;
+}
+
 __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
   return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)p;
 }
@@ -220,7 +228,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 // BPRE (FCD_PREC_BF16X3 only): the weights arrive already split into three bf16 planes
 // ([plane][row][K], fcd_pack_weight_*_x3), so only the activation fragments are split in registers.
 template <int BM, int BN, int WM, int WN, int S, int PREC, bool N16 = false, bool BPRE = false>
-__global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const GatherArgs p, const unsigned in_bytes,
+__global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const GatherArgs p, const size_t in_bytes,
                                                                        const unsigned w_bytes) {
   static_assert(!N16 || (BN == 32 && WN == 1 && PREC == FCD_PREC_F32), "N16 shape");
   constexpr int BNC = N16 ? 16 : BN;            // output channels this block computes
@@ -261,7 +269,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
     rowoff[r] = off;
   }
 
-  const i32x4 rin = make_rsrc(p.in, in_bytes);
+  // input window of this tile: from its first image on (lane offsets are relative to it)
+  const int n0 = __builtin_amdgcn_readfirstlane(min(tm * BM, p.M - 1) / ghw);
+  const size_t in_start = (size_t)n0 * p.IH * p.IW * p.Cin * 4;
+  const i32x4 rin = make_rsrc(reinterpret_cast<const char*>(p.in) + in_start, window_bytes(in_bytes, in_start));
   const i32x4 rw = make_rsrc(p.w + (long)phase * p.w_phase_stride, w_bytes);
   const unsigned lds0 = lds_addr_of(smem);
 
@@ -280,7 +291,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
       const int n = m / ghw, rem = m - n * ghw;
       const int a = rem / p.GW, b = rem - a * p.GW;
       const int ih0 = a * p.istride - pad_h, iw0 = b * p.istride - pad_w;
-      a_base[i] = ((n * p.IH + ih0) * p.IW + iw0) * p.Cin * 4;
+      a_base[i] = (((n - n0) * p.IH + ih0) * p.IW + iw0) * p.Cin * 4;
       for (int t = 0; t < p.KH; ++t) a_mh[i] |= (unsigned)(ih0 + t >= 0 && ih0 + t < p.IH) << t;
       for (int t = 0; t < p.KW; ++t) a_mw[i] |= (unsigned)(iw0 + t >= 0 && iw0 + t < p.IW) << t;
     }
@@ -791,8 +802,8 @@ __device__ __forceinline__ void read_vec(const float* p, float* out) {
 // M16: at most 16 output channels (v_mfma_f32_16x16x4_f32 tiles; the A stage keeps its 32-column
 // LDS slot, only columns 0..15 are read).
 template <int BM, int BN, int WM, int WN, int S, int PREC, bool M16 = false>
-__global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_dma_kernel(const WgradArgs p, const unsigned gs_bytes,
-                                                                      const unsigned xb_bytes) {
+__global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_dma_kernel(const WgradArgs p, const size_t gs_bytes,
+                                                                      const size_t xb_bytes) {
   static_assert(!M16 || (BM == 32 && WM == 1 && PREC == FCD_PREC_F32), "M16 shape");
   constexpr int NW = WM * WN;
   constexpr int WTM = BM / WM, WTN = BN / WN;
@@ -814,13 +825,16 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_dma_kernel(const Wgra
   const int ks = bid / ntile, tile = bid - ks * ntile;
   const int tn = tile % p.tiles_n, tm = tile / p.tiles_n;
 
-  const i32x4 rgs = make_rsrc(p.gs, gs_bytes);
-  const i32x4 rxb = make_rsrc(p.xb, xb_bytes);
   const unsigned lds0 = lds_addr_of(smem);
 
   const int kt0 = ks * p.ktiles_per_split;
   const int kt1 = min(p.ktiles, kt0 + p.ktiles_per_split);
   const int nk = kt1 - kt0;
+  // operand windows of this K range: from its first pixel row (gs) / first image (xb) on
+  const int px0 = kt0 * 32, n0 = __builtin_amdgcn_readfirstlane(px0 / (p.GH * p.GW));
+  const size_t gs_start = (size_t)px0 * p.OP * 4, xb_start = (size_t)n0 * p.BH * p.BW * p.IP * 4;
+  const i32x4 rgs = make_rsrc(reinterpret_cast<const char*>(p.gs) + gs_start, window_bytes(gs_bytes, gs_start));
+  const i32x4 rxb = make_rsrc(reinterpret_cast<const char*>(p.xb) + xb_start, window_bytes(xb_bytes, xb_start));
 
   // A (gs): lane -> (pixel row within the instruction, 4 columns)
   // M16 rotates the columns of LDS row kq (by 16*((kq>>1)&1) in A, 16*(kq&3) in B) so that the
@@ -862,14 +876,14 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_dma_kernel(const Wgra
   auto issue_one = [&](int q) {
     if (q < AL) {
       const unsigned okm = (0u - (unsigned)(a_colok & (a_px[q] < p.P))) & live;
-      const unsigned voff = ((unsigned)((a_px[q] * p.OP + o0) * 4) & okm) | (OOB & ~okm);
+      const unsigned voff = ((unsigned)(((a_px[q] - px0) * p.OP + o0) * 4) & okm) | (OOB & ~okm);
       dma16(rgs, voff, la + q * (NW * 1024));
       a_px[q] += 32;
     } else {
       const int i = q - AL;
       const int ih = b_a[i] * p.stride - p.pad + th, iw = b_b[i] * p.stride - p.pad + tw;
       const unsigned okm = (0u - (unsigned)(b_colok & (b_px[i] < p.P) & (ih >= 0) & (ih < p.BH) & (iw >= 0) & (iw < p.BW))) & live;
-      const unsigned voff = ((unsigned)((((b_n[i] * p.BH + ih) * p.BW + iw) * p.IP + ci) * 4) & okm) | (OOB & ~okm);
+      const unsigned voff = ((unsigned)(((((b_n[i] - n0) * p.BH + ih) * p.BW + iw) * p.IP + ci) * 4) & okm) | (OOB & ~okm);
       dma16(rxb, voff, lb + i * (NW * 1024));
       b_px[i] += 32;
       b_b[i] += 32;
@@ -1103,8 +1117,8 @@ __device__ __forceinline__ unsigned plane_off(int row, int chunk, int row_bytes)
 }
 
 template <int BM, int WM, int WN>
-__global__ __launch_bounds__(512) void conv_wgrad_x3p_kernel(const WgradArgs p, const unsigned gs_bytes,
-                                                             const unsigned xb_bytes) {
+__global__ __launch_bounds__(512) void conv_wgrad_x3p_kernel(const WgradArgs p, const size_t gs_bytes,
+                                                             const size_t xb_bytes) {
   constexpr int BN = 128, KT = 32, NT = 512;
   constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
   static_assert(WM * WN == 8 && TM >= 1 && TN >= 1 && BM % 64 == 0, "shape");
@@ -1126,8 +1140,13 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3p_kernel(const WgradArgs p, 
   const int kt1 = min(p.ktiles, kt0 + p.ktiles_per_split);
   const int nk = kt1 - kt0;
 
-  __amdgpu_buffer_rsrc_t rgs = __builtin_amdgcn_make_buffer_rsrc((void*)p.gs, (short)0, (int)gs_bytes, 0x00020000);
-  __amdgpu_buffer_rsrc_t rxb = __builtin_amdgcn_make_buffer_rsrc((void*)p.xb, (short)0, (int)xb_bytes, 0x00020000);
+  // operand windows of this K range: from its first pixel row (gs) / first image (xb) on
+  const int px0 = kt0 * KT, n0 = __builtin_amdgcn_readfirstlane(px0 / (p.GH * p.GW));
+  const size_t gs_start = (size_t)px0 * p.OP * 4, xb_start = (size_t)n0 * p.BH * p.BW * p.IP * 4;
+  __amdgpu_buffer_rsrc_t rgs = __builtin_amdgcn_make_buffer_rsrc((char*)p.gs + gs_start, (short)0,
+                                                                 (int)window_bytes(gs_bytes, gs_start), 0x00020000);
+  __amdgpu_buffer_rsrc_t rxb = __builtin_amdgcn_make_buffer_rsrc((char*)p.xb + xb_start, (short)0,
+                                                                 (int)window_bytes(xb_bytes, xb_start), 0x00020000);
 
   // ---- global -> register tile loads
   const int a_row = tid / C4A, a_c4 = tid % C4A;
@@ -1157,7 +1176,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3p_kernel(const WgradArgs p, 
       const int px = a_px + RPA * q_;
       // validity folded into the offset with ALU selects (no branches: the loop body stays one basic block)
       const unsigned okm = 0u - (unsigned)((int)a_colok & (int)(px < p.P));
-      const unsigned voff = ((unsigned)((px * p.OP + o0) * 4) & okm) | (OOB & ~okm);
+      const unsigned voff = ((unsigned)(((px - px0) * p.OP + o0) * 4) & okm) | (OOB & ~okm);
       ra[q_] = __builtin_amdgcn_raw_buffer_load_b128(rgs, (int)voff, 0, 0);
       if (q_ == AL - 1) a_px += KT;
     } else {
@@ -1165,7 +1184,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3p_kernel(const WgradArgs p, 
       const int ih = b_a[i] * p.stride - p.pad + th, iw = b_b[i] * p.stride - p.pad + tw;
       const unsigned okm = 0u - (unsigned)((int)b_colok & (int)(b_px[i] < p.P) & (int)(ih >= 0) & (int)(ih < p.BH) &
                                            (int)(iw >= 0) & (int)(iw < p.BW));
-      const unsigned voff = ((unsigned)((((b_n[i] * p.BH + ih) * p.BW + iw) * p.IP + ci) * 4) & okm) | (OOB & ~okm);
+      const unsigned voff = ((unsigned)(((((b_n[i] - n0) * p.BH + ih) * p.BW + iw) * p.IP + ci) * 4) & okm) | (OOB & ~okm);
       rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rxb, (int)voff, 0, 0);
       b_px[i] += KT;
       int nb = b_b[i] + step_b;
@@ -1335,8 +1354,8 @@ constexpr int H7_CW = 64;     // gradient columns per workgroup
 constexpr int H7_XW = 80;     // pixels per LDS ring row: 70 used, padded to 5 whole DMA instructions
 constexpr int H7_WAVES = 7;
 __global__ __launch_bounds__(64 * H7_WAVES) void wgrad7_halo_kernel(const WgradArgs p, const int rows, const int R,
-                                                                   const int nch, const unsigned gs_bytes,
-                                                                   const unsigned xb_bytes) {
+                                                                   const int nch, const size_t gs_bytes,
+                                                                   const size_t xb_bytes) {
   __shared__ float4 Xs[8 * H7_XW * 4];     // [ring slot][pixel][4 chunks = 16 channels]
   __shared__ float4 Gs[2 * H7_CW * 4];     // [buffer][pixel][4 chunks = 16 output channels]
   const int lane = threadIdx.x & 63;
@@ -1345,8 +1364,10 @@ __global__ __launch_bounds__(64 * H7_WAVES) void wgrad7_halo_kernel(const WgradA
   const int ncg = p.IP / 16;
   const int cg = blockIdx.y % ncg, n = blockIdx.y / ncg;
   const int x0 = ch * H7_CW, y0 = r * rows, y1 = min(p.GH, y0 + rows);
-  const i32x4 rgs = make_rsrc(p.gs, gs_bytes);
-  const i32x4 rxb = make_rsrc(p.xb, xb_bytes);
+  // operand windows: this workgroup's image
+  const size_t gs_start = (size_t)n * p.GH * p.GW * p.OP * 4, xb_start = (size_t)n * p.BH * p.BW * p.IP * 4;
+  const i32x4 rgs = make_rsrc(reinterpret_cast<const char*>(p.gs) + gs_start, window_bytes(gs_bytes, gs_start));
+  const i32x4 rxb = make_rsrc(reinterpret_cast<const char*>(p.xb) + xb_start, window_bytes(xb_bytes, xb_start));
   const unsigned lx = lds_addr_of(Xs), lg0 = lds_addr_of(Gs);
   const int lpx = lane >> 2, lc = lane & 3;      // pixel within a DMA instruction, 16-byte chunk
 
@@ -1354,13 +1375,13 @@ __global__ __launch_bounds__(64 * H7_WAVES) void wgrad7_halo_kernel(const WgradA
   auto issue_x = [&](int j, int yy) {
     const int px = j * 16 + lpx, gx = x0 - 3 + px;
     const bool ok = px < H7_CW + 6 && yy >= 0 && yy < p.BH && gx >= 0 && gx < p.BW;
-    const unsigned voff = ok ? (unsigned)((((n * p.BH + yy) * p.BW + gx) * p.IP + cg * 16 + lc * 4) * 4) : OOB;
+    const unsigned voff = ok ? (unsigned)(((yy * p.BW + gx) * p.IP + cg * 16 + lc * 4) * 4) : OOB;
     dma16(rxb, voff, lx + (unsigned)((((yy + 16) & 7) * H7_XW * 4 + j * 64) * 16));
   };
   auto issue_g = [&](int j, int y) {
     const int px = j * 16 + lpx, gx = x0 + px;
     const bool ok = y < y1 && gx < p.GW && lc * 4 < p.OP;
-    const unsigned voff = ok ? (unsigned)((((n * p.GH + y) * p.GW + gx) * p.OP + lc * 4) * 4) : OOB;
+    const unsigned voff = ok ? (unsigned)(((y * p.GW + gx) * p.OP + lc * 4) * 4) : OOB;
     dma16(rgs, voff, lg0 + (unsigned)(((y & 1) * H7_CW * 4 + j * 64) * 16));
   };
   // the 9 instructions of one row step, dealt round-robin to the 7 waves
@@ -1424,14 +1445,15 @@ __global__ __launch_bounds__(64 * H7_WAVES) void wgrad7_halo_kernel(const WgradA
 constexpr int F7_CW = 32;     // output columns per workgroup
 constexpr int F7_XW = 40;     // pixels per LDS ring row: 38 used, 10 whole DMA instructions
 __global__ __launch_bounds__(64 * H7_WAVES) void conv7_halo_kernel(const GatherArgs p, const int rows, const int nch,
-                                                                  const unsigned in_bytes) {
+                                                                  const size_t in_bytes) {
   __shared__ float4 Xs[8 * F7_XW * 16];          // [ring slot][pixel][16 chunks = 64 channels]
   __shared__ float Rs[2 * H7_WAVES * F7_CW * 16]; // [row parity][wave][pixel][16 output channels]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ch = blockIdx.x % nch, r = blockIdx.x / nch, n = blockIdx.y;
   const int x0 = ch * F7_CW, y0 = r * rows, y1 = min(p.OH, y0 + rows);
-  const i32x4 rin = make_rsrc(p.in, in_bytes);
+  const size_t in_start = (size_t)n * p.IH * p.IW * 64 * 4;      // input window: this workgroup's image
+  const i32x4 rin = make_rsrc(reinterpret_cast<const char*>(p.in) + in_start, window_bytes(in_bytes, in_start));
   const unsigned lx = lds_addr_of(Xs);
   const int dpx = lane >> 4, dslot = lane & 15;      // pixel within a DMA instruction, chunk slot
 
@@ -1439,7 +1461,7 @@ __global__ __launch_bounds__(64 * H7_WAVES) void conv7_halo_kernel(const GatherA
   auto issue_x = [&](int j, int yy) {
     const int px = j * 4 + dpx, gx = x0 - 3 + px;
     const bool ok = px < F7_CW + 6 && yy >= 0 && yy < p.IH && gx >= 0 && gx < p.IW;
-    const unsigned voff = ok ? (unsigned)((((n * p.IH + yy) * p.IW + gx) * 64 + 4 * (dslot ^ (px & 15))) * 4) : OOB;
+    const unsigned voff = ok ? (unsigned)(((yy * p.IW + gx) * 64 + 4 * (dslot ^ (px & 15))) * 4) : OOB;
     dma16(rin, voff, lx + (unsigned)((((yy + 16) & 7) * F7_XW * 16 + j * 64) * 16));
   };
   auto issue_row = [&](int yy) {
@@ -1524,20 +1546,22 @@ constexpr int C12_WAVES = 7;          // MFMA waves (one per tap row); an eighth
 constexpr int C12_ROWB = C12_XW * 12 * 2;                 // bytes per plane row
 constexpr int C12_SLOT = 3 * C12_ROWB;
 __global__ __launch_bounds__(64 * (C12_WAVES + 1)) void conv7_c12_halo_x3_kernel(const GatherArgs p, const int rows, const int nch,
-                                                                                const unsigned in_bytes) {
+                                                                                const size_t in_bytes) {
   __shared__ __attribute__((aligned(16))) unsigned char Xp[8 * C12_SLOT];
   __shared__ __attribute__((aligned(16))) float Rs[2 * C12_WAVES * 32 * 64];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ch = blockIdx.x % nch, rr = blockIdx.x / nch, n = blockIdx.y;
   const int x0 = ch * C12_CW, y0 = rr * rows, y1 = min(p.OH, y0 + rows);
-  __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, (short)0, (int)in_bytes, 0x00020000);
+  const size_t in_start = (size_t)n * p.IH * p.IW * 12 * 4;      // input window: this workgroup's image
+  __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((char*)p.in + in_start, (short)0,
+                                                                 (int)window_bytes(in_bytes, in_start), 0x00020000);
 
   // ---- input rows: float4 f of the 72-pixel row = pixel f / 3, channels 4 (f % 3) ..; 216 per row
   auto load_f4 = [&](int f, int yy) -> u32x4 {
     const int lpx = f / 3, lc4 = f - lpx * 3, gx = x0 - 3 + lpx;
     const unsigned okm = 0u - (unsigned)((int)(f < C12_XW * 3) & (int)(yy >= 0) & (int)(yy < p.IH) & (int)(gx >= 0) & (int)(gx < p.IW));
-    const unsigned voff = ((unsigned)((((n * p.IH + yy) * p.IW + gx) * 12 + lc4 * 4) * 4) & okm) | (OOB & ~okm);
+    const unsigned voff = ((unsigned)(((yy * p.IW + gx) * 12 + lc4 * 4) * 4) & okm) | (OOB & ~okm);
     return __builtin_amdgcn_raw_buffer_load_b128(rin, (int)voff, 0, 0);
   };
   auto store_f4 = [&](const u32x4 v, int f, int yy) {
@@ -1791,7 +1815,7 @@ template <int BM, int BN, int WM, int WN>
 int launch_gather(const GatherArgs& a, int precision, hipStream_t st) {
   note_kernel("conv_gather_dma_kernel<%d, %d, %d, %d, 3, %d, false, false>", BM, BN, WM, WN, precision);
   dim3 grid(a.tiles_m * a.tiles_n, a.nphase * a.splitk);
-  const unsigned in_bytes = (unsigned)((size_t)a.N * a.IH * a.IW * a.Cin * 4);
+  const size_t in_bytes = (size_t)a.N * a.IH * a.IW * a.Cin * 4;
   const unsigned w_bytes = (unsigned)((size_t)a.Cout * a.K * 4);
   if (precision == FCD_PREC_BF16)
     hipLaunchKernelGGL((conv_gather_dma_kernel<BM, BN, WM, WN, 3, FCD_PREC_BF16>), grid, dim3(64 * WM * WN), 0, st, a, in_bytes, w_bytes);
@@ -1806,8 +1830,8 @@ template <int BM, int BN, int WM, int WN>
 int launch_wgrad(const WgradArgs& a, int precision, hipStream_t st) {
   note_kernel("conv_wgrad_dma_kernel<%d, %d, %d, %d, 3, %d, false>", BM, BN, WM, WN, precision);
   dim3 grid(a.tiles_m * a.tiles_n, a.splitk);
-  const unsigned gs_bytes = (unsigned)((size_t)a.P * a.OP * 4);
-  const unsigned xb_bytes = (unsigned)((size_t)a.N * a.BH * a.BW * a.IP * 4);
+  const size_t gs_bytes = (size_t)a.P * a.OP * 4;
+  const size_t xb_bytes = (size_t)a.N * a.BH * a.BW * a.IP * 4;
   if (precision == FCD_PREC_BF16)
     hipLaunchKernelGGL((conv_wgrad_dma_kernel<BM, BN, WM, WN, 3, FCD_PREC_BF16>), grid, dim3(64 * WM * WN), 0, st, a, gs_bytes, xb_bytes);
   else if (precision == FCD_PREC_BF16X3)
@@ -1836,9 +1860,14 @@ int validate_conv(const FcdConvDesc* d) {
                 "conv: phase %d writes outside the %dx%d output", ph, d->OH, d->OW);
   }
   FCD_REQUIRE((long)d->N * d->GH * d->GW < (1l << 31), "conv: too many output pixels");
-  FCD_REQUIRE((size_t)d->N * d->IH * d->IW * d->Cin * 4 < (1ull << 31) &&
-                  (size_t)d->nphase * d->Cout * d->KH * d->KW * d->Cin * 4 < (1ull << 31),
-              "conv: operands must be smaller than 2 GiB (32-bit buffer offsets)");
+  // the tensors themselves may exceed 2 GiB; a workgroup addresses a window of the input that starts at the
+  // first image its (at most 256) output rows touch, with 32-bit offsets inside the window
+  const size_t image_bytes = (size_t)d->IH * d->IW * d->Cin * 4;
+  const size_t span_images = (size_t)fcd_cdiv(256, (long)d->GH * d->GW) + 1;
+  FCD_REQUIRE(image_bytes * span_images < (1ull << 31),
+              "conv: %zu input images of %zu bytes per workgroup exceed the 2 GiB window (32-bit lane offsets)",
+              span_images, image_bytes);
+  FCD_REQUIRE((size_t)d->nphase * d->Cout * d->KH * d->KW * d->Cin * 4 < (1ull << 31), "conv: weights must be smaller than 2 GiB");
   return FCD_OK;
 }
 
@@ -1973,14 +2002,14 @@ int run_gather(const FcdConvDesc* d, GatherArgs& a, hipStream_t st) {
     const int nch = fcd_cdiv(d->GW, C12_CW), R = fcd_cdiv(d->GH, rows);
     note_kernel("conv7_c12_halo_x3_kernel");
     hipLaunchKernelGGL(conv7_c12_halo_x3_kernel, dim3(nch * R, d->N), dim3(64 * (C12_WAVES + 1)), 0, st, a, rows, nch,
-                       (unsigned)((size_t)a.N * a.IH * a.IW * a.Cin * 4));
+                       (size_t)a.N * a.IH * a.IW * a.Cin * 4);
     return fcd_check_launch("conv7_c12_halo_x3");
   }
   if (const int rows = halo7_fwd_rows(d, a)) {
     const int nch = fcd_cdiv(d->GW, F7_CW), R = fcd_cdiv(d->GH, rows);
     note_kernel("conv7_halo_kernel");
     hipLaunchKernelGGL(conv7_halo_kernel, dim3(nch * R, d->N), dim3(64 * H7_WAVES), 0, st, a, rows, nch,
-                       (unsigned)((size_t)a.N * a.IH * a.IW * a.Cin * 4));
+                       (size_t)a.N * a.IH * a.IW * a.Cin * 4);
     return fcd_check_launch("conv7_halo");
   }
   if (wants_split_weights(d)) {
@@ -1988,7 +2017,8 @@ int run_gather(const FcdConvDesc* d, GatherArgs& a, hipStream_t st) {
     a.tiles_n = fcd_cdiv(d->Cout, bn);
     a.w_phase_stride = (long)d->Cout * a.K * 3 / 2;      // three bf16 planes, in units of 4 bytes
     dim3 grid(a.tiles_m * a.tiles_n, a.nphase * a.splitk);
-    const unsigned in_bytes = (unsigned)((size_t)a.N * a.IH * a.IW * a.Cin * 4), w_bytes = (unsigned)((size_t)a.Cout * a.K * 6);
+    const size_t in_bytes = (size_t)a.N * a.IH * a.IW * a.Cin * 4;
+    const unsigned w_bytes = (unsigned)((size_t)a.Cout * a.K * 6);
     if (gather_big_tile(d)) {
       a.tiles_m = fcd_cdiv(a.M, 256);
       grid = dim3(a.tiles_m * a.tiles_n, a.nphase * a.splitk);
@@ -2025,7 +2055,7 @@ int run_gather(const FcdConvDesc* d, GatherArgs& a, hipStream_t st) {
     dim3 grid(a.tiles_m * a.tiles_n, a.nphase * a.splitk);
     note_kernel("conv_gather_dma_kernel<128, 32, 4, 1, 3, 0, true, false>");
     hipLaunchKernelGGL((conv_gather_dma_kernel<128, 32, 4, 1, 3, FCD_PREC_F32, true>), grid, dim3(256), 0, st, a,
-                       (unsigned)((size_t)a.N * a.IH * a.IW * a.Cin * 4), (unsigned)((size_t)a.Cout * a.K * 4));
+                       (size_t)a.N * a.IH * a.IW * a.Cin * 4, (unsigned)((size_t)a.Cout * a.K * 4));
     rc = fcd_check_launch("conv_gather");
   } else if (bm == 128 && bn == 32) rc = launch_gather<128, 32, 4, 1>(a, d->precision, st);
   else if (bm == 128 && bn == 64) rc = launch_gather<128, 64, 4, 2>(a, d->precision, st);
@@ -2171,9 +2201,10 @@ static int validate_wgrad(const FcdWgradDesc* d) {
   FCD_REQUIRE(d->KH > 0 && d->KW > 0 && d->stride >= 1 && d->pad >= 0, "wgrad: kernel");
   FCD_REQUIRE(d->splitk >= 0 && d->splitk <= 4096, "wgrad: splitk=%d", d->splitk);
   FCD_REQUIRE((long)d->N * d->GH * d->GW < (1l << 31), "wgrad: too many pixels");
-  FCD_REQUIRE((size_t)d->N * d->GH * d->GW * d->OP * 4 < (1ull << 31) &&
-                  (size_t)d->N * d->BH * d->BW * d->IP * 4 < (1ull << 31),
-              "wgrad: operands must be smaller than 2 GiB (32-bit buffer offsets)");
+  // the tensors themselves may exceed 2 GiB; a workgroup addresses the window of its own pixel range
+  // (checked against the resolved split in fcd_conv_wgrad), an image at the least
+  FCD_REQUIRE((size_t)d->GH * d->GW * d->OP * 4 < (1ull << 30) && (size_t)d->BH * d->BW * d->IP * 4 < (1ull << 30),
+              "wgrad: one image of an operand must be smaller than 1 GiB (32-bit lane offsets)");
   return FCD_OK;
 }
 
@@ -2205,6 +2236,13 @@ extern "C" int fcd_conv_wgrad(const FcdWgradDesc* d, const float* gsmall, const 
   a.ktiles_per_split = fcd_cdiv(a.ktiles, a.splitk);
   a.splitk = fcd_cdiv(a.ktiles, a.ktiles_per_split);
   a.accumulate = d->accumulate;
+  {
+    // 32-bit lane offsets inside a workgroup's window: its pixel rows of gs, the images those touch of xb
+    const size_t px = (size_t)a.ktiles_per_split * 32;
+    const size_t images = px / ((size_t)d->GH * d->GW) + 2;
+    FCD_REQUIRE(px * d->OP * 4 < (1ull << 31) && images * d->BH * d->BW * d->IP * 4 < (1ull << 31),
+                "wgrad: a K split of %zu pixels spans more than 2 GiB of an operand; raise splitk", px);
+  }
   hipStream_t st = fcd_stream(stream);
   int h_rows = 0, h_R = 0, h_nch = 0;
   const int halo = halo7_plan(d, &h_rows, &h_R, &h_nch);
@@ -2213,14 +2251,14 @@ extern "C" int fcd_conv_wgrad(const FcdWgradDesc* d, const float* gsmall, const 
     dim3 grid(h_nch * h_R, d->N * (d->IP / 16));
     note_kernel("wgrad7_halo_kernel");
     hipLaunchKernelGGL(wgrad7_halo_kernel, grid, dim3(64 * H7_WAVES), 0, st, a, h_rows, h_R, h_nch,
-                       (unsigned)((size_t)a.P * a.OP * 4), (unsigned)((size_t)a.N * a.BH * a.BW * a.IP * 4));
+                       (size_t)a.P * a.OP * 4, (size_t)a.N * a.BH * a.BW * a.IP * 4);
     rc = fcd_check_launch("conv_wgrad");
   } else if (d->O <= 16 && d->precision != FCD_PREC_BF16) {   // exact fp32 16-row kernel, also under BF16X3
     a.tiles_m = 1; a.tiles_n = fcd_cdiv(a.ND, 128);
     dim3 grid(a.tiles_n, a.splitk);
     note_kernel("conv_wgrad_dma_kernel<32, 128, 1, 4, 3, 0, true>");
     hipLaunchKernelGGL((conv_wgrad_dma_kernel<32, 128, 1, 4, 3, FCD_PREC_F32, true>), grid, dim3(256), 0, st, a,
-                       (unsigned)((size_t)a.P * a.OP * 4), (unsigned)((size_t)a.N * a.BH * a.BW * a.IP * 4));
+                       (size_t)a.P * a.OP * 4, (size_t)a.N * a.BH * a.BW * a.IP * 4);
     rc = fcd_check_launch("conv_wgrad");
   } else if (d->O <= 32) {
     a.tiles_m = fcd_cdiv(d->O, 32); a.tiles_n = fcd_cdiv(a.ND, 128);
@@ -2231,7 +2269,7 @@ extern "C" int fcd_conv_wgrad(const FcdWgradDesc* d, const float* gsmall, const 
     const int bm = wgrad_bm(d);
     a.tiles_m = fcd_cdiv(d->O, bm); a.tiles_n = fcd_cdiv(a.ND, 128);
     dim3 grid(a.tiles_m * a.tiles_n, a.splitk);
-    const unsigned gsb = (unsigned)((size_t)a.P * a.OP * 4), xbb = (unsigned)((size_t)a.N * a.BH * a.BW * a.IP * 4);
+    const size_t gsb = (size_t)a.P * a.OP * 4, xbb = (size_t)a.N * a.BH * a.BW * a.IP * 4;
     note_kernel("conv_wgrad_x3p_kernel<%d, %d, %d>", bm, bm == 64 ? 2 : 4, bm == 64 ? 4 : 2);
     if (bm == 64) hipLaunchKernelGGL((conv_wgrad_x3p_kernel<64, 2, 4>), grid, dim3(512), 0, st, a, gsb, xbb);
     else if (bm == 128) hipLaunchKernelGGL((conv_wgrad_x3p_kernel<128, 4, 2>), grid, dim3(512), 0, st, a, gsb, xbb);

@@ -256,10 +256,11 @@ class FCDSolver(nn.Module):
 
     @staticmethod
     def _pair_fits(x, widest: int) -> bool:
-        """A paired batch doubles every activation: pair only while the largest one (full resolution,
-        `widest` channels, fp32) stays below the library's 2 GiB operand limit (32-bit buffer offsets)."""
-        n, _, h, w = x.shape
-        return 2 * n * h * w * max(int(widest), 12) * 4 < (1 << 31)
+        """A paired batch doubles every activation.  The library's kernels address a window of a few images
+        with 32-bit lane offsets (tensors themselves may exceed 2 GiB), so what has to fit is two images of
+        the largest activation (full resolution, `widest` channels, fp32)."""
+        _, _, h, w = x.shape
+        return 2 * h * w * max(int(widest), 12) * 4 < (1 << 31)
 
     @staticmethod
     def _feat_l1(real_feats, other_feats):
