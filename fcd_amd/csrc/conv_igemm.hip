@@ -1529,6 +1529,164 @@ __global__ __launch_bounds__(64 * H7_WAVES) void conv7_halo_kernel(const GatherA
   }
 }
 
+// FCD_PREC_BF16X3 form of conv7_halo_kernel (7x7, 64 -> <= 16 channels: the generator's last layer).  The exact-fp32
+// kernel above is bound by the 16-wide fp32 MFMA (32 cycles per 16 px x 16 co x 4 k); six bf16 16x16x32 MFMAs over
+// the (h, m, l) pieces do eight times the k in 96 cycles.  Every input row is fetched ONCE (global -> registers),
+// split once into three bf16 planes and kept in an 8-slot LDS ring [slot][plane][40 pixels][64 channels]; each of
+// the 7 MFMA waves owns tap row th, holds its 7 x 64 x 16 weights pre-split in registers (168 VGPRs) and reads its
+// A fragments straight from the planes: lane (pixel = lane & 15, kq = lane >> 4) takes the 16-byte chunk
+// 4 (s & 1) + kq of pixel P = 16 mt + pixel + tw for k32-step s = 2 tw + (channel half).  Chunk slot XOR
+// ((P >> 1) & 7): the 16 pixels of a read pass cover all 64 banks.  An eighth (helper) wave loads and splits the
+// input row five rows ahead, sums the 7 partial tiles of the previous row in a fixed order (wave 0 .. 6), applies
+// bias / LeakyReLU and stores.  One barrier per output row.
+constexpr int F7X_PLANE = F7_XW * 128;        // bytes per plane of a ring slot (64 bf16 per pixel)
+constexpr int F7X_SLOT = 3 * F7X_PLANE;
+__global__ __launch_bounds__(64 * (H7_WAVES + 1)) void conv7_halo_x3_kernel(const GatherArgs p, const int rows, const int nch,
+                                                                            const size_t in_bytes) {
+  __shared__ __attribute__((aligned(16))) unsigned char Xp[8 * F7X_SLOT];
+  __shared__ __attribute__((aligned(16))) float Rs[2 * H7_WAVES * F7_CW * 16];   // [row parity][wave][pixel][16 co]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ch = blockIdx.x % nch, rr = blockIdx.x / nch, n = blockIdx.y;
+  const int x0 = ch * F7_CW, y0 = rr * rows, y1 = min(p.OH, y0 + rows);
+  const size_t in_start = (size_t)n * p.IH * p.IW * 64 * 4;      // input window: this workgroup's image
+  __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((char*)p.in + in_start, (short)0,
+                                                                 (int)window_bytes(in_bytes, in_start), 0x00020000);
+
+  // ---- input rows: float4 f of the 40-pixel row = pixel f >> 4, channels 4 (f & 15) ..; 38 pixels are used
+  auto load_f4 = [&](int f, int yy) -> u32x4 {
+    const int lpx = f >> 4, c4 = f & 15, gx = x0 - 3 + lpx;
+    const unsigned okm = 0u - (unsigned)((int)(lpx < F7_CW + 6) & (int)(yy >= 0) & (int)(yy < p.IH) & (int)(gx >= 0) & (int)(gx < p.IW));
+    const unsigned voff = ((unsigned)(((yy * p.IW + gx) * 64 + c4 * 4) * 4) & okm) | (OOB & ~okm);
+    return __builtin_amdgcn_raw_buffer_load_b128(rin, (int)voff, 0, 0);
+  };
+  auto store_f4 = [&](const u32x4 v, int f, int yy) {
+    const int lpx = f >> 4, c4 = f & 15;
+    if (lpx >= F7_CW + 6) return;
+    unsigned char* dst = Xp + ((yy + 16) & 7) * F7X_SLOT + lpx * 128 + (((c4 >> 1) ^ ((lpx >> 1) & 7)) << 4) + 8 * (c4 & 1);
+    const float f0 = __uint_as_float(v.x), f1 = __uint_as_float(v.y), f2 = __uint_as_float(v.z), f3 = __uint_as_float(v.w);
+    const unsigned h0 = cvt_pk_bf16(f0, f1), h1 = cvt_pk_bf16(f2, f3);
+    const float r0 = f0 - __uint_as_float(h0 << 16), r1 = f1 - __uint_as_float(h0 & 0xFFFF0000u);
+    const float r2 = f2 - __uint_as_float(h1 << 16), r3 = f3 - __uint_as_float(h1 & 0xFFFF0000u);
+    const unsigned m0 = cvt_pk_bf16(r0, r1), m1 = cvt_pk_bf16(r2, r3);
+    const float s0 = r0 - __uint_as_float(m0 << 16), s1 = r1 - __uint_as_float(m0 & 0xFFFF0000u);
+    const float s2 = r2 - __uint_as_float(m1 << 16), s3 = r3 - __uint_as_float(m1 & 0xFFFF0000u);
+    *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(dst + F7X_PLANE) = make_uint2(m0, m1);
+    *reinterpret_cast<uint2*>(dst + 2 * F7X_PLANE) = make_uint2(cvt_pk_bf16(s0, s1), cvt_pk_bf16(s2, s3));
+  };
+  // prologue: rows y0-3 .. y0+3, all 512 threads (640 float4 per row)
+  for (int yy = y0 - 3; yy <= y0 + 3; ++yy) {
+    const u32x4 v0 = load_f4(tid, yy), v1 = load_f4(tid + 512, yy);
+    store_f4(v0, tid, yy);
+    if (tid + 512 < F7_XW * 16) store_f4(v1, tid + 512, yy);
+  }
+
+  if (wave == H7_WAVES) {
+    // ================= helper wave
+    u32x4 nr[10];
+#pragma unroll
+    for (int j = 0; j < 10; ++j) nr[j] = load_f4(lane + 64 * j, y0 + 4);
+    __syncthreads();                       // prologue rows visible
+    auto sum_store = [&](int y) {
+      const float* R0 = Rs + (y & 1) * H7_WAVES * (F7_CW * 16);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int idx = lane + 64 * j, px = idx >> 2, co = 4 * (idx & 3);   // float4 (pixel, 4 output channels)
+        float4 v = *reinterpret_cast<const float4*>(R0 + idx * 4);
+#pragma unroll
+        for (int w7 = 1; w7 < H7_WAVES; ++w7) {
+          const float4 t = *reinterpret_cast<const float4*>(R0 + w7 * (F7_CW * 16) + idx * 4);
+          v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+        if (x0 + px >= p.OW || co >= p.CoutP) continue;
+        float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (co + e < p.Cout) {
+            float u = vv[e];
+            if (p.bias) u += p.bias[co + e];
+            vv[e] = u > 0.f ? u : u * p.act_slope;
+          } else {
+            vv[e] = 0.f;
+          }
+        }
+        *reinterpret_cast<float4*>(p.out + (((long)n * p.OH + y) * p.OW + x0 + px) * p.CoutP + co) =
+            make_float4(vv[0], vv[1], vv[2], vv[3]);
+      }
+    };
+    for (int y = y0; y < y1; ++y) {
+      // every MFMA wave is past row y-1 (barrier of row y-1), whose oldest input row y-4 sat in slot (y+4) & 7
+#pragma unroll
+      for (int j = 0; j < 10; ++j) store_f4(nr[j], lane + 64 * j, y + 4);
+#pragma unroll
+      for (int j = 0; j < 10; ++j) nr[j] = load_f4(lane + 64 * j, y + 5);
+      if (y > y0) sum_store(y - 1);
+      __syncthreads();                     // row y+4 visible, partial tiles of row y complete
+    }
+    sum_store(y1 - 1);
+    return;
+  }
+
+  // ================= MFMA waves: tap row th = wave; B fragment of k32-step s: lane (co = lane & 15, kq = lane >> 4)
+  // holds channels 32 (s & 1) + 8 kq .. +7 of tap (th, s >> 1)
+  const int c16 = lane & 15, kq = lane >> 4;
+  bf16x8_t wh[14], wm[14], wl[14];
+#pragma unroll
+  for (int s2 = 0; s2 < 14; ++s2) {
+    const float* src = p.w + (long)c16 * p.K + (wave * 7 + (s2 >> 1)) * 64 + 32 * (s2 & 1) + 8 * kq;
+    f32x8 f;
+    if (c16 < p.Cout) {
+      const float4 lo = *reinterpret_cast<const float4*>(src), hi = *reinterpret_cast<const float4*>(src + 4);
+      f = f32x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    } else {
+      f = f32x8{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    }
+    split3(f, wh[s2], wm[s2], wl[s2]);
+  }
+  __syncthreads();
+
+  for (int y = y0; y < y1; ++y) {
+    const unsigned char* Xrow = Xp + ((y + wave - 3 + 16) & 7) * F7X_SLOT;
+    f32x4 acc[2], acca[2], accb[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) acc[mt] = acca[mt] = accb[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s2 = 0; s2 < 14; ++s2) {
+      bf16x8_t ah[2], am[2], al[2];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const int P = 16 * mt + c16 + (s2 >> 1);
+        const unsigned char* a = Xrow + P * 128 + (((4 * (s2 & 1) + kq) ^ ((P >> 1) & 7)) << 4);
+        ah[mt] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(a));
+        am[mt] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(a + F7X_PLANE));
+        al[mt] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(a + 2 * F7X_PLANE));
+      }
+      // small terms first, into two side accumulators (three independent chains per pixel tile)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) acca[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mt], wh[s2], acca[mt], 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) accb[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], wl[s2], accb[mt], 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) acca[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[mt], wm[s2], acca[mt], 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) accb[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[mt], wh[s2], accb[mt], 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) acca[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], wm[s2], acca[mt], 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], wh[s2], acc[mt], 0, 0, 0);
+    }
+    // D[pixel = 4 kq + e][co = c16] -> Rs[row parity][wave][pixel][co]; this parity was last read by the helper
+    // for row y-2, before the barrier of row y-1
+    float* R = Rs + ((y & 1) * H7_WAVES + wave) * (F7_CW * 16);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) R[(16 * mt + 4 * kq + e) * 16 + c16] = acc[mt][e] + (acca[mt][e] + accb[mt][e]);
+    __syncthreads();
+  }
+}
+
 // 7x7, stride-1, pad-3 convolution from 12 physical channels to 64 (the generator's first layer, 11 -> 64,
 // and the last layer's data gradient, 10 -> 64), FCD_PREC_BF16X3, "halo" form.  The generic gather kernel pulls
 // every input pixel through L2 -> LDS once per tap (49 times: 1.2 GB per 32-sample launch against 25 MB of
@@ -2007,6 +2165,12 @@ int run_gather(const FcdConvDesc* d, GatherArgs& a, hipStream_t st) {
   }
   if (const int rows = halo7_fwd_rows(d, a)) {
     const int nch = fcd_cdiv(d->GW, F7_CW), R = fcd_cdiv(d->GH, rows);
+    if (d->precision == FCD_PREC_BF16X3 && d->CoutP % 4 == 0 && !getenv("FCD_NO_HALO7X")) {
+      note_kernel("conv7_halo_x3_kernel");
+      hipLaunchKernelGGL(conv7_halo_x3_kernel, dim3(nch * R, d->N), dim3(64 * (H7_WAVES + 1)), 0, st, a, rows, nch,
+                         (size_t)a.N * a.IH * a.IW * a.Cin * 4);
+      return fcd_check_launch("conv7_halo_x3");
+    }
     note_kernel("conv7_halo_kernel");
     hipLaunchKernelGGL(conv7_halo_kernel, dim3(nch * R, d->N), dim3(64 * H7_WAVES), 0, st, a, rows, nch,
                        (size_t)a.N * a.IH * a.IW * a.Cin * 4);

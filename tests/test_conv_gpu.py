@@ -271,9 +271,15 @@ def test_conv_7x7_halo_forward(dev, geom, prec):
     ref = F.leaky_relu(F.conv2d(x.double(), w.double(), None if b is None else b.double(), 1, 3), 0.2)
     xd = to_nhwc(x, g.IP).to(dev)
     d = g.fwd_desc(N, H, W, precision=prec, act_slope=0.2)
+    d.splitk = 1           # (small problems would otherwise split K and take the generic kernel)
     out = ops.conv_gather(d, xd, pack_for(d, w.to(dev), g, "fwd"), bias=None if b is None else b.to(dev))
     assert relerr(from_nhwc(out.cpu(), O).double(), ref) <= TOL[prec]
     assert float(out[..., O:].abs().max()) == 0.0 if g.OP > O else True     # padded channels stay zero
+    from fcd_amd import _lib as L
+    assert L.load().fcd_last_conv_kernel() == (b"conv7_halo_x3_kernel" if prec == 2 else b"conv7_halo_kernel")
+    if prec == 2:
+        # the split-once BF16X3 kernel is fp32-faithful: as close to float64 as the exact-fp32 halo kernel
+        assert relerr(from_nhwc(out.cpu(), O).double(), ref) <= 1e-6
 
 
 @pytest.mark.parametrize("shape", [(256, 256, 3, 1, 1, 4, 32, 32), (300, 36, 3, 1, 1, 3, 17, 13), (128, 64, 4, 2, 1, 2, 64, 64),
