@@ -846,7 +846,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_dma_kernel(const Wgra
   const bool a_colok = o0 < p.OP;
   int a_px[AL];
 #pragma unroll
-  for (int i = 0; i < AL; ++i) a_px[i] = kt0 * 32 + (i * NW + wave) * ARPI + a_row;
+  for (int i = 0; i < AL; ++i) a_px[i] = (i * NW + wave) * ARPI + a_row;      // relative to px0
 
   // B (xb gathered at this lane's tap): column -> (tap, ci)
   const int b_row = lane / (BN / 4);
@@ -859,12 +859,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_dma_kernel(const Wgra
   int b_px[BL], b_n[BL], b_a[BL], b_b[BL];
 #pragma unroll
   for (int i = 0; i < BL; ++i) {
-    b_px[i] = kt0 * 32 + (i * NW + wave) * BRPI + b_row;
-    b_n[i] = b_px[i] / ghw;
-    const int rem = b_px[i] - b_n[i] * ghw;
+    b_px[i] = (i * NW + wave) * BRPI + b_row;                    // relative to px0
+    const int bn = (px0 + b_px[i]) / ghw, rem = px0 + b_px[i] - bn * ghw;
+    b_n[i] = bn - n0;                                            // relative to the window's first image
     b_a[i] = rem / p.GW;
     b_b[i] = rem - b_a[i] * p.GW;
   }
+  const int prel = p.P - px0;                                    // pixels from the window's start to the end of the tensor
 
   constexpr int ND = AL + BL;
   unsigned live = 0, la = 0, lb = 0;
@@ -875,15 +876,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_dma_kernel(const Wgra
   };
   auto issue_one = [&](int q) {
     if (q < AL) {
-      const unsigned okm = (0u - (unsigned)(a_colok & (a_px[q] < p.P))) & live;
-      const unsigned voff = ((unsigned)(((a_px[q] - px0) * p.OP + o0) * 4) & okm) | (OOB & ~okm);
+      const unsigned okm = (0u - (unsigned)(a_colok & (a_px[q] < prel))) & live;
+      const unsigned voff = ((unsigned)((a_px[q] * p.OP + o0) * 4) & okm) | (OOB & ~okm);
       dma16(rgs, voff, la + q * (NW * 1024));
       a_px[q] += 32;
     } else {
       const int i = q - AL;
       const int ih = b_a[i] * p.stride - p.pad + th, iw = b_b[i] * p.stride - p.pad + tw;
-      const unsigned okm = (0u - (unsigned)(b_colok & (b_px[i] < p.P) & (ih >= 0) & (ih < p.BH) & (iw >= 0) & (iw < p.BW))) & live;
-      const unsigned voff = ((unsigned)(((((b_n[i] - n0) * p.BH + ih) * p.BW + iw) * p.IP + ci) * 4) & okm) | (OOB & ~okm);
+      const unsigned okm = (0u - (unsigned)(b_colok & (b_px[i] < prel) & (ih >= 0) & (ih < p.BH) & (iw >= 0) & (iw < p.BW))) & live;
+      const unsigned voff = ((unsigned)((((b_n[i] * p.BH + ih) * p.BW + iw) * p.IP + ci) * 4) & okm) | (OOB & ~okm);
       dma16(rxb, voff, lb + i * (NW * 1024));
       b_px[i] += 32;
       b_b[i] += 32;
@@ -1152,7 +1153,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3p_kernel(const WgradArgs p, 
   const int a_row = tid / C4A, a_c4 = tid % C4A;
   const int o0 = tm * BM + a_c4 * 4;
   const bool a_colok = o0 < p.OP;
-  int a_px = kt0 * KT + a_row;                                   // + RPA per pass, + KT per tile
+  int a_px = a_row;                                              // relative to px0; + RPA per pass, + KT per tile
   const int b_row = tid / C4B, b_c4 = tid % C4B;
   const int nd = tn * BN + b_c4 * 4;
   const bool b_colok = nd < p.ND;
@@ -1162,12 +1163,13 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3p_kernel(const WgradArgs p, 
   int b_px[BL], b_n[BL], b_a[BL], b_b[BL];
 #pragma unroll
   for (int i = 0; i < BL; ++i) {
-    b_px[i] = kt0 * KT + b_row + RPB * i;
-    b_n[i] = b_px[i] / ghw;
-    const int rem = b_px[i] - b_n[i] * ghw;
+    b_px[i] = b_row + RPB * i;                                   // relative to px0
+    const int bn = (px0 + b_px[i]) / ghw, rem = px0 + b_px[i] - bn * ghw;
+    b_n[i] = bn - n0;                                            // relative to the window's first image
     b_a[i] = rem / p.GW;
     b_b[i] = rem - b_a[i] * p.GW;
   }
+  const int prel = p.P - px0;                                    // pixels from the window's start to the end of the tensor
   // one K-tile = KT pixels further = step_n images + step_a rows + step_b columns (branch-free carries)
   const int step_n = KT / ghw, step_r = KT - step_n * ghw, step_a = step_r / p.GW, step_b = step_r - step_a * p.GW;
   u32x4 ra[AL], rb[BL];
@@ -1175,16 +1177,16 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3p_kernel(const WgradArgs p, 
     if (q_ < AL) {
       const int px = a_px + RPA * q_;
       // validity folded into the offset with ALU selects (no branches: the loop body stays one basic block)
-      const unsigned okm = 0u - (unsigned)((int)a_colok & (int)(px < p.P));
-      const unsigned voff = ((unsigned)(((px - px0) * p.OP + o0) * 4) & okm) | (OOB & ~okm);
+      const unsigned okm = 0u - (unsigned)((int)a_colok & (int)(px < prel));
+      const unsigned voff = ((unsigned)((px * p.OP + o0) * 4) & okm) | (OOB & ~okm);
       ra[q_] = __builtin_amdgcn_raw_buffer_load_b128(rgs, (int)voff, 0, 0);
       if (q_ == AL - 1) a_px += KT;
     } else {
       const int i = q_ - AL;
       const int ih = b_a[i] * p.stride - p.pad + th, iw = b_b[i] * p.stride - p.pad + tw;
-      const unsigned okm = 0u - (unsigned)((int)b_colok & (int)(b_px[i] < p.P) & (int)(ih >= 0) & (int)(ih < p.BH) &
+      const unsigned okm = 0u - (unsigned)((int)b_colok & (int)(b_px[i] < prel) & (int)(ih >= 0) & (int)(ih < p.BH) &
                                            (int)(iw >= 0) & (int)(iw < p.BW));
-      const unsigned voff = ((unsigned)(((((b_n[i] - n0) * p.BH + ih) * p.BW + iw) * p.IP + ci) * 4) & okm) | (OOB & ~okm);
+      const unsigned voff = ((unsigned)((((b_n[i] * p.BH + ih) * p.BW + iw) * p.IP + ci) * 4) & okm) | (OOB & ~okm);
       rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rxb, (int)voff, 0, 0);
       b_px[i] += KT;
       int nb = b_b[i] + step_b;
@@ -1536,7 +1538,7 @@ __global__ __launch_bounds__(64 * H7_WAVES) void conv7_halo_kernel(const GatherA
 // the 7 MFMA waves owns tap row th, holds its 7 x 64 x 16 weights pre-split in registers (168 VGPRs) and reads its
 // A fragments straight from the planes: lane (pixel = lane & 15, kq = lane >> 4) takes the 16-byte chunk
 // 4 (s & 1) + kq of pixel P = 16 mt + pixel + tw for k32-step s = 2 tw + (channel half).  Chunk slot XOR
-// ((P >> 1) & 7): the 16 pixels of a read pass cover all 64 banks.  An eighth (helper) wave loads and splits the
+// (P & 7): the lane groups of a ds_read_b128 ({0-3, 12-15, 20-27}, ...) then cover all 64 banks for every tap shift.  An eighth (helper) wave loads and splits the
 // input row five rows ahead, sums the 7 partial tiles of the previous row in a fixed order (wave 0 .. 6), applies
 // bias / LeakyReLU and stores.  One barrier per output row.
 constexpr int F7X_PLANE = F7_XW * 128;        // bytes per plane of a ring slot (64 bf16 per pixel)
@@ -1563,7 +1565,7 @@ __global__ __launch_bounds__(64 * (H7_WAVES + 1)) void conv7_halo_x3_kernel(cons
   auto store_f4 = [&](const u32x4 v, int f, int yy) {
     const int lpx = f >> 4, c4 = f & 15;
     if (lpx >= F7_CW + 6) return;
-    unsigned char* dst = Xp + ((yy + 16) & 7) * F7X_SLOT + lpx * 128 + (((c4 >> 1) ^ ((lpx >> 1) & 7)) << 4) + 8 * (c4 & 1);
+    unsigned char* dst = Xp + ((yy + 16) & 7) * F7X_SLOT + lpx * 128 + (((c4 >> 1) ^ (lpx & 7)) << 4) + 8 * (c4 & 1);
     const float f0 = __uint_as_float(v.x), f1 = __uint_as_float(v.y), f2 = __uint_as_float(v.z), f3 = __uint_as_float(v.w);
     const unsigned h0 = cvt_pk_bf16(f0, f1), h1 = cvt_pk_bf16(f2, f3);
     const float r0 = f0 - __uint_as_float(h0 << 16), r1 = f1 - __uint_as_float(h0 & 0xFFFF0000u);
@@ -1651,30 +1653,32 @@ __global__ __launch_bounds__(64 * (H7_WAVES + 1)) void conv7_halo_x3_kernel(cons
     f32x4 acc[2], acca[2], accb[2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) acc[mt] = acca[mt] = accb[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // software pipeline over (k32-step, pixel tile): the fragments of the next unit are in flight under the six
+    // MFMAs of the current one (left to the compiler, every unit's reads were waited for right after issue)
+    bf16x8_t fh[2], fm[2], fl[2];
+    auto load_frag = [&](int s2, int mt) {
+      const int P = 16 * mt + c16 + (s2 >> 1);
+      const unsigned char* a = Xrow + P * 128 + (((4 * (s2 & 1) + kq) ^ (P & 7)) << 4);
+      fh[mt] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(a));
+      fm[mt] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(a + F7X_PLANE));
+      fl[mt] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(a + 2 * F7X_PLANE));
+    };
+    // small terms into two side accumulators, the main product into a third: three chains per pixel tile
+    auto mfma6 = [&](int s2, int mt) {
+      acca[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fl[mt], wh[s2], acca[mt], 0, 0, 0);
+      accb[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[mt], wl[s2], accb[mt], 0, 0, 0);
+      acca[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fm[mt], wm[s2], acca[mt], 0, 0, 0);
+      accb[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fm[mt], wh[s2], accb[mt], 0, 0, 0);
+      acca[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[mt], wm[s2], acca[mt], 0, 0, 0);
+      acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[mt], wh[s2], acc[mt], 0, 0, 0);
+    };
+    load_frag(0, 0);
 #pragma unroll
     for (int s2 = 0; s2 < 14; ++s2) {
-      bf16x8_t ah[2], am[2], al[2];
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
-        const int P = 16 * mt + c16 + (s2 >> 1);
-        const unsigned char* a = Xrow + P * 128 + (((4 * (s2 & 1) + kq) ^ ((P >> 1) & 7)) << 4);
-        ah[mt] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(a));
-        am[mt] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(a + F7X_PLANE));
-        al[mt] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(a + 2 * F7X_PLANE));
-      }
-      // small terms first, into two side accumulators (three independent chains per pixel tile)
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt) acca[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mt], wh[s2], acca[mt], 0, 0, 0);
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt) accb[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], wl[s2], accb[mt], 0, 0, 0);
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt) acca[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[mt], wm[s2], acca[mt], 0, 0, 0);
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt) accb[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[mt], wh[s2], accb[mt], 0, 0, 0);
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt) acca[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], wm[s2], acca[mt], 0, 0, 0);
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], wh[s2], acc[mt], 0, 0, 0);
+      load_frag(s2, 1);
+      mfma6(s2, 0);
+      if (s2 + 1 < 14) load_frag(s2 + 1, 0);
+      mfma6(s2, 1);
     }
     // D[pixel = 4 kq + e][co = c16] -> Rs[row parity][wave][pixel][co]; this parity was last read by the helper
     // for row y-2, before the barrier of row y-1

@@ -198,19 +198,6 @@ __global__ __launch_bounds__(256) void finalize_kernel(const double* __restrict_
   }
 }
 
-__global__ __launch_bounds__(256) void affine_grad_kernel(const float* __restrict__ s12, float* __restrict__ dgamma,
-                                                          float* __restrict__ dbeta, int N, int C, int accumulate) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  double a = 0.0, b = 0.0;
-  for (int n = 0; n < N; ++n) {
-    b += (double)s12[((long)n * C + c) * 2 + 0];
-    a += (double)s12[((long)n * C + c) * 2 + 1];
-  }
-  if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)a : (float)a;
-  if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)b : (float)b;
-}
-
 __global__ __launch_bounds__(256) void in_apply_kernel(const float* __restrict__ z, const float* __restrict__ mean,
                                                        const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const float* __restrict__ res,
@@ -249,11 +236,36 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                            const float* __restrict__ s12, float* __restrict__ dz, long HW,
                                                            int C, ColPlan pl, float act_slope, int use_running,
-                                                           const float* __restrict__ beta) {
+                                                           const float* __restrict__ beta, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, int N, int accumulate) {
   const int n = blockIdx.y, chunk = blockIdx.x;
   const int c4b = pl.c4b;
   const int cbase = blockIdx.z * 1024;
   const int tx = threadIdx.x % c4b, ty = threadIdx.x / c4b;
+  if ((dgamma || dbeta) && chunk == pl.chunks - 1 && n == 0) {
+    // The affine gradients (sums of s12 over the images, in double, in image order) ride in one block per channel
+    // block instead of a launch of their own between the finalize and this kernel: one thread per channel, the
+    // loads of 16 images in flight at a time.
+    for (int cl = threadIdx.x; cl < c4b * 4; cl += 256) {
+      const int c = cbase + cl;
+      if (c >= C) break;
+      double a = 0.0, b = 0.0;
+      for (int i0 = 0; i0 < N; i0 += 16) {
+        float2 v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+          if (i0 + u < N) v[u] = *reinterpret_cast<const float2*>(s12 + ((long)(i0 + u) * C + c) * 2);
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+          if (i0 + u < N) {
+            b += (double)v[u].x;
+            a += (double)v[u].y;
+          }
+      }
+      if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)a : (float)a;
+      if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)b : (float)b;
+    }
+  }
   if (ty >= pl.rows || cbase / 4 + tx >= pl.c4) return;
   const float inv_hw = 1.f / (float)HW;
   const bool need_mask = act_slope != 1.f;
@@ -560,13 +572,8 @@ extern "C" int fcd_instnorm_bwd(const float* gy, const float* y, const float* z,
                      (float*)nullptr, (float*)nullptr, (long)HW, C, pl.chunks, 0.f, 0);
   rc = fcd_check_launch("instnorm_bwd/finalize");
   if (rc) return rc;
-  if (dgamma || dbeta) {
-    hipLaunchKernelGGL(affine_grad_kernel, dim3(fcd_cdiv(C, 256)), dim3(256), 0, st, s12, dgamma, dbeta, N, C, accumulate);
-    rc = fcd_check_launch("instnorm_bwd/affine");
-    if (rc) return rc;
-  }
   hipLaunchKernelGGL(in_bwd_apply_kernel, dim3(pl.chunks, N, pl.cblocks), dim3(256), 0, st, gy, y, z, mean, rstd, gamma, s12,
-                     dz, (long)HW, C, pl, act_slope, use_running, beta);
+                     dz, (long)HW, C, pl, act_slope, use_running, beta, dgamma, dbeta, N, accumulate);
   return fcd_check_launch("instnorm_bwd/apply");
 }
 

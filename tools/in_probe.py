@@ -10,14 +10,14 @@ def t(fn, iters=30):
     for _ in range(iters): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e3
-for shape in ((16, 32, 32, 256), (16, 128, 128, 64)):
+for shape in ((32, 32, 32, 256), (32, 128, 128, 64)):
     n, h, w, c = shape
     z = torch.randn(shape, device=dev); gy = torch.randn(shape, device=dev)
     gamma = torch.rand(c, device=dev) + 0.5; beta = torch.randn(c, device=dev) * 0.1
     mean, rstd, _ = ops.instnorm_stats(z)
     y = ops.instnorm_apply(z, mean, rstd, gamma, beta, 0.0)
     mb = z.numel() * 4 / 1e6
-    for rep in range(2):
+    for rep in range(1):
         print(shape, "stats      %.1f us" % t(lambda: ops.instnorm_stats(z)), " (%.0f MB)" % mb)
         print(shape, "apply      %.1f us" % t(lambda: ops.instnorm_apply(z, mean, rstd, gamma, beta, 0.0, out=y)))
         print(shape, "bwd with y %.1f us" % t(lambda: ops.instnorm_bwd(gy, y, z, mean, rstd, gamma, 0.0, False)))
