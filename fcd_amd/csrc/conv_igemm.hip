@@ -1433,6 +1433,146 @@ __global__ __launch_bounds__(64 * H7_WAVES) void wgrad7_halo_kernel(const WgradA
   }
 }
 
+// FCD_PREC_BF16X3 form of wgrad7_halo_kernel.  Same ownership (image, 16-channel group, 64-column strip, row
+// range; wave th = tap row, one accumulator set per tap column), but the 16x16x4 fp32 MFMAs (32 cycles per 4
+// pixels) become six bf16 16x16x32 ones over the (h, m, l) pieces (96 cycles per 32 pixels).  Gradient and input
+// rows are fetched once (global -> registers) by an eighth (helper) wave, split once into three bf16 planes
+// [pixel][16 channels] and kept in LDS (input: 8-slot ring of 80-pixel rows; gradient: two buffers).  The MFMA's K
+// axis is the pixel axis, so the operand fragments (8 consecutive pixels of one channel per lane) come from
+// ds_read_b64_tr_b16 transposed reads; a tap column is a shift of the pixel row.  Pixel rows are 32 bytes; bit 7 of
+// the byte offset is flipped for pixels with bit 3 set, so that the two 4-pixel blocks a read instruction's 32 lanes
+// fetch (8 pixels apart) sit in different halves of the banks at every shift.
+constexpr int W7X_XPLANE = H7_XW * 32;          // bytes per plane of an input ring slot
+constexpr int W7X_XSLOT = 3 * W7X_XPLANE;
+constexpr int W7X_GPLANE = H7_CW * 32;
+constexpr int W7X_GBUF = 3 * W7X_GPLANE;
+__device__ __forceinline__ unsigned w7x_px_off(int px) { return (unsigned)(px * 32) ^ (unsigned)(((px >> 3) & 1) << 7); }
+
+__global__ __launch_bounds__(64 * (H7_WAVES + 1)) void wgrad7_halo_x3_kernel(const WgradArgs p, const int rows, const int R,
+                                                                             const int nch, const size_t gs_bytes,
+                                                                             const size_t xb_bytes) {
+  __shared__ __attribute__((aligned(16))) unsigned char Xp[8 * W7X_XSLOT];
+  __shared__ __attribute__((aligned(16))) unsigned char Gp[2 * W7X_GBUF];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ch = blockIdx.x % nch, r = blockIdx.x / nch;
+  const int ncg = p.IP / 16;
+  const int cg = blockIdx.y % ncg, n = blockIdx.y / ncg;
+  const int x0 = ch * H7_CW, y0 = r * rows, y1 = min(p.GH, y0 + rows);
+  const size_t gs_start = (size_t)n * p.GH * p.GW * p.OP * 4, xb_start = (size_t)n * p.BH * p.BW * p.IP * 4;
+  __amdgpu_buffer_rsrc_t rgs = __builtin_amdgcn_make_buffer_rsrc((char*)p.gs + gs_start, (short)0,
+                                                                 (int)window_bytes(gs_bytes, gs_start), 0x00020000);
+  __amdgpu_buffer_rsrc_t rxb = __builtin_amdgcn_make_buffer_rsrc((char*)p.xb + xb_start, (short)0,
+                                                                 (int)window_bytes(xb_bytes, xb_start), 0x00020000);
+
+  // float4 f of an input row = pixel f >> 2 (of 80; 70 used), channels 4 (f & 3) .. of this group; of a gradient
+  // row = pixel f >> 2 (of 64), output channels 4 (f & 3) .. (zeros from OP on)
+  auto load_x = [&](int f, int yy) -> u32x4 {
+    const int px = f >> 2, c4 = f & 3, gx = x0 - 3 + px;
+    const unsigned okm = 0u - (unsigned)((int)(px < H7_CW + 6) & (int)(yy >= 0) & (int)(yy < p.BH) & (int)(gx >= 0) & (int)(gx < p.BW));
+    const unsigned voff = ((unsigned)(((yy * p.BW + gx) * p.IP + cg * 16 + c4 * 4) * 4) & okm) | (OOB & ~okm);
+    return __builtin_amdgcn_raw_buffer_load_b128(rxb, (int)voff, 0, 0);
+  };
+  auto load_g = [&](int f, int y) -> u32x4 {
+    const int px = f >> 2, c4 = f & 3, gx = x0 + px;
+    const unsigned okm = 0u - (unsigned)((int)(y < y1) & (int)(gx < p.GW) & (int)(c4 * 4 < p.OP));
+    const unsigned voff = ((unsigned)(((y * p.GW + gx) * p.OP + c4 * 4) * 4) & okm) | (OOB & ~okm);
+    return __builtin_amdgcn_raw_buffer_load_b128(rgs, (int)voff, 0, 0);
+  };
+  auto split_store = [&](const u32x4 v, unsigned char* dst, int plane_bytes) {
+    const float f0 = __uint_as_float(v.x), f1 = __uint_as_float(v.y), f2 = __uint_as_float(v.z), f3 = __uint_as_float(v.w);
+    const unsigned h0 = cvt_pk_bf16(f0, f1), h1 = cvt_pk_bf16(f2, f3);
+    const float r0 = f0 - __uint_as_float(h0 << 16), r1 = f1 - __uint_as_float(h0 & 0xFFFF0000u);
+    const float r2 = f2 - __uint_as_float(h1 << 16), r3 = f3 - __uint_as_float(h1 & 0xFFFF0000u);
+    const unsigned m0 = cvt_pk_bf16(r0, r1), m1 = cvt_pk_bf16(r2, r3);
+    const float s0 = r0 - __uint_as_float(m0 << 16), s1 = r1 - __uint_as_float(m0 & 0xFFFF0000u);
+    const float s2 = r2 - __uint_as_float(m1 << 16), s3 = r3 - __uint_as_float(m1 & 0xFFFF0000u);
+    *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(dst + plane_bytes) = make_uint2(m0, m1);
+    *reinterpret_cast<uint2*>(dst + 2 * plane_bytes) = make_uint2(cvt_pk_bf16(s0, s1), cvt_pk_bf16(s2, s3));
+  };
+  auto store_x = [&](const u32x4 v, int f, int yy) {
+    split_store(v, Xp + ((yy + 16) & 7) * W7X_XSLOT + w7x_px_off(f >> 2) + 8 * (f & 3), W7X_XPLANE);
+  };
+  auto store_g = [&](const u32x4 v, int f, int y) {
+    split_store(v, Gp + (y & 1) * W7X_GBUF + w7x_px_off(f >> 2) + 8 * (f & 3), W7X_GPLANE);
+  };
+  // prologue: input rows y0-3 .. y0+3 and gradient row y0, all 512 threads (320 / 256 float4 per row)
+  for (int yy = y0 - 3; yy <= y0 + 3; ++yy)
+    if (tid < H7_XW * 4) store_x(load_x(tid, yy), tid, yy);
+  if (tid < H7_CW * 4) store_g(load_g(tid, y0), tid, y0);
+
+  if (wave == H7_WAVES) {
+    // ================= helper wave: input row y+4 and gradient row y+1 while the others work on row y
+    u32x4 nx[5], ng[4];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) nx[j] = load_x(lane + 64 * j, y0 + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ng[j] = load_g(lane + 64 * j, y0 + 1);
+    __syncthreads();
+    for (int y = y0; y < y1; ++y) {
+      // every MFMA wave is past row y-1: input row y-4 (slot (y+4) & 7) and gradient buffer (y+1) & 1 are free
+#pragma unroll
+      for (int j = 0; j < 5; ++j) store_x(nx[j], lane + 64 * j, y + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) store_g(ng[j], lane + 64 * j, y + 1);
+#pragma unroll
+      for (int j = 0; j < 5; ++j) nx[j] = load_x(lane + 64 * j, y + 5);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ng[j] = load_g(lane + 64 * j, y + 2);
+      __syncthreads();
+    }
+    return;
+  }
+
+  // ================= MFMA waves: tap row th = wave.  A = g (M = output channel), B = x (N = input channel), K = 32 pixels.
+  // lane (c = lane & 15, kq = lane >> 4) receives channel c, pixels 8 kq + 4 j .. + 3 from read j; it supplies the
+  // address of pixel 8 kq + 4 j + (c >> 2), channels 4 (c & 3) ..
+  const int c16 = lane & 15, kq = lane >> 4, th = wave;
+  const int q = c16 >> 2, pp = c16 & 3;
+  auto frag = [&](const unsigned char* base, int px) -> bf16x8_t {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + w7x_px_off(px) + 8 * pp));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + w7x_px_off(px + 4) + 8 * pp));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+  };
+  f32x4 acc[7], acca[7], accb[7];
+#pragma unroll
+  for (int t = 0; t < 7; ++t) acc[t] = acca[t] = accb[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+  for (int y = y0; y < y1; ++y) {
+    const unsigned char* Xrow = Xp + ((y + th - 3 + 16) & 7) * W7X_XSLOT;
+    const unsigned char* Grow = Gp + (y & 1) * W7X_GBUF;
+#pragma unroll
+    for (int ks = 0; ks < H7_CW / 32; ++ks) {
+      const int px = 32 * ks + 8 * kq + q;
+      const bf16x8_t gh = frag(Grow, px), gm = frag(Grow + W7X_GPLANE, px), gl = frag(Grow + 2 * W7X_GPLANE, px);
+#pragma unroll
+      for (int t = 0; t < 7; ++t) {
+        const bf16x8_t xh = frag(Xrow, px + t), xm = frag(Xrow + W7X_XPLANE, px + t), xl = frag(Xrow + 2 * W7X_XPLANE, px + t);
+        acca[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gl, xh, acca[t], 0, 0, 0);
+        accb[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gh, xl, accb[t], 0, 0, 0);
+        acca[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gm, xm, acca[t], 0, 0, 0);
+        accb[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gm, xh, accb[t], 0, 0, 0);
+        acca[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gh, xm, acca[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gh, xh, acc[t], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  // D[o = 4 kq + e][i = c16] of tap (th, t)
+  float* __restrict__ dst = p.slab + (long)((n * R + r) * nch + ch) * p.O * p.ND;
+#pragma unroll
+  for (int t = 0; t < 7; ++t) {
+    const int col = (th * 7 + t) * p.IP + cg * 16 + c16;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int o = 4 * kq + e;
+      if (o < p.O) dst[(long)o * p.ND + col] = acc[t][e] + (acca[t][e] + accb[t][e]);
+    }
+  }
+}
+
 // Forward form of the same idea: a 7x7, stride-1, pad-3 convolution from 64 channels to at most 16 (the
 // generator's last layer, 64 -> 10 at 128x128).  The generic 16-wide gather kernel streams the input once
 // per tap through L2 -> LDS (49 x 134 MB per 32-sample launch), which is what bounds it at about three times
@@ -2417,9 +2557,15 @@ extern "C" int fcd_conv_wgrad(const FcdWgradDesc* d, const float* gsmall, const 
   if (halo) {                                           // exact fp32, input rows loaded once for all 49 taps
     a.splitk = halo;
     dim3 grid(h_nch * h_R, d->N * (d->IP / 16));
-    note_kernel("wgrad7_halo_kernel");
-    hipLaunchKernelGGL(wgrad7_halo_kernel, grid, dim3(64 * H7_WAVES), 0, st, a, h_rows, h_R, h_nch,
-                       (size_t)a.P * a.OP * 4, (size_t)a.N * a.BH * a.BW * a.IP * 4);
+    if (d->precision == FCD_PREC_BF16X3 && !getenv("FCD_NO_WGRAD7X")) {
+      note_kernel("wgrad7_halo_x3_kernel");
+      hipLaunchKernelGGL(wgrad7_halo_x3_kernel, grid, dim3(64 * (H7_WAVES + 1)), 0, st, a, h_rows, h_R, h_nch,
+                         (size_t)a.P * a.OP * 4, (size_t)a.N * a.BH * a.BW * a.IP * 4);
+    } else {
+      note_kernel("wgrad7_halo_kernel");
+      hipLaunchKernelGGL(wgrad7_halo_kernel, grid, dim3(64 * H7_WAVES), 0, st, a, h_rows, h_R, h_nch,
+                         (size_t)a.P * a.OP * 4, (size_t)a.N * a.BH * a.BW * a.IP * 4);
+    }
     rc = fcd_check_launch("conv_wgrad");
   } else if (d->O <= 16 && d->precision != FCD_PREC_BF16) {   // exact fp32 16-row kernel, also under BF16X3
     a.tiles_m = 1; a.tiles_n = fcd_cdiv(a.ND, 128);

@@ -184,7 +184,9 @@ def test_wgrad_7x7_halo(dev, geom, prec):
     d = g.wgrad_desc(N, H, W, precision=prec)
     gyd, xd = to_nhwc(gy, g.OP).to(dev), to_nhwc(x, g.IP).to(dev)
     dw = ops.conv_wgrad(d, gyd, xd)
-    assert relerr(dw.cpu(), ref) <= 1e-5
+    from fcd_amd import _lib as L
+    assert L.load().fcd_last_conv_kernel() == (b"wgrad7_halo_x3_kernel" if prec == 2 else b"wgrad7_halo_kernel")
+    assert relerr(dw.cpu(), ref) <= (1e-6 if prec == 2 else 1e-5)     # the split-once BF16X3 kernel is fp32-faithful
     d.accumulate = 1
     dw2 = ops.conv_wgrad(d, gyd, xd, dw.clone())
     assert relerr(dw2.cpu(), 2 * ref) <= 1e-5
