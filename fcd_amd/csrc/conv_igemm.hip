@@ -2010,6 +2010,152 @@ __global__ __launch_bounds__(64 * (C12_WAVES + 1)) void conv7_c12_halo_x3_kernel
   __syncthreads();
 }
 
+// Weight gradient of the 7x7, stride-1, pad-3 convolution from 12 physical channels (the generator's first layer),
+// FCD_PREC_BF16X3, halo form.  The generic kernel gathers the 588 (tap, channel) columns of every pixel row from
+// global memory for each of its 5 column tiles and splits them in every workgroup.  Here a workgroup owns (image,
+// 64-column strip, row range, 32 output channels); a helper wave fetches every input row and gradient row once,
+// splits them once into three bf16 planes in LDS (input: 8-slot ring of 72-pixel rows [pixel][12 channels];
+// gradient: two buffers [pixel][32 channels]).  With 12 channels per pixel the 7 taps of a tap row are 84
+// consecutive values of a ring row, so for tap row th the B matrix (K = pixel, N = (tw, ci)) is simply "row x =
+// the 96 values starting at pixel x" -- overlapping rows of the same memory, read with ds_read_b64_tr_b16 (the
+// MFMA's K axis is the pixel axis).  Wave th = tap row: 32 x 96 accumulators, K = 16 pixels per MFMA.
+constexpr int W12_GPLANE = C12_CW * 64;          // bytes per plane of a gradient buffer ([pixel][32 channels] bf16)
+constexpr int W12_GBUF = 3 * W12_GPLANE;
+__global__ __launch_bounds__(64 * (C12_WAVES + 1)) void wgrad7_c12_halo_x3_kernel(const WgradArgs p, const int rows, const int R,
+                                                                                 const int nch, const int halves,
+                                                                                 const size_t gs_bytes, const size_t xb_bytes) {
+  __shared__ __attribute__((aligned(16))) unsigned char Xp[8 * C12_SLOT];       // (columns 84 .. 95 of the last pixels stay inside the 72-pixel row)
+  __shared__ __attribute__((aligned(16))) unsigned char Gp[2 * W12_GBUF];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ch = blockIdx.x % nch, r = blockIdx.x / nch;
+  const int half = blockIdx.y % halves, n = blockIdx.y / halves;
+  const int x0 = ch * C12_CW, y0 = r * rows, y1 = min(p.GH, y0 + rows);
+  const size_t gs_start = (size_t)n * p.GH * p.GW * p.OP * 4, xb_start = (size_t)n * p.BH * p.BW * 12 * 4;
+  __amdgpu_buffer_rsrc_t rgs = __builtin_amdgcn_make_buffer_rsrc((char*)p.gs + gs_start, (short)0,
+                                                                 (int)window_bytes(gs_bytes, gs_start), 0x00020000);
+  __amdgpu_buffer_rsrc_t rxb = __builtin_amdgcn_make_buffer_rsrc((char*)p.xb + xb_start, (short)0,
+                                                                 (int)window_bytes(xb_bytes, xb_start), 0x00020000);
+
+  // float4 f of an input row = pixel f / 3 (of 72; 70 used), channels 4 (f % 3) ..; of a gradient row = pixel f >> 3
+  // (of 64), channels 32 half + 4 (f & 7) ..
+  auto load_x = [&](int f, int yy) -> u32x4 {
+    const int px = f / 3, c4 = f - px * 3, gx = x0 - 3 + px;
+    const unsigned okm = 0u - (unsigned)((int)(f < C12_XW * 3) & (int)(yy >= 0) & (int)(yy < p.BH) & (int)(gx >= 0) & (int)(gx < p.BW));
+    const unsigned voff = ((unsigned)(((yy * p.BW + gx) * 12 + c4 * 4) * 4) & okm) | (OOB & ~okm);
+    return __builtin_amdgcn_raw_buffer_load_b128(rxb, (int)voff, 0, 0);
+  };
+  auto load_g = [&](int f, int y) -> u32x4 {
+    const int px = f >> 3, c = 32 * half + 4 * (f & 7), gx = x0 + px;
+    const unsigned okm = 0u - (unsigned)((int)(y < y1) & (int)(gx < p.GW) & (int)(c < p.OP));
+    const unsigned voff = ((unsigned)(((y * p.GW + gx) * p.OP + c) * 4) & okm) | (OOB & ~okm);
+    return __builtin_amdgcn_raw_buffer_load_b128(rgs, (int)voff, 0, 0);
+  };
+  auto split_store = [&](const u32x4 v, unsigned char* dst, int plane_bytes) {
+    const float f0 = __uint_as_float(v.x), f1 = __uint_as_float(v.y), f2 = __uint_as_float(v.z), f3 = __uint_as_float(v.w);
+    const unsigned h0 = cvt_pk_bf16(f0, f1), h1 = cvt_pk_bf16(f2, f3);
+    const float r0 = f0 - __uint_as_float(h0 << 16), r1 = f1 - __uint_as_float(h0 & 0xFFFF0000u);
+    const float r2 = f2 - __uint_as_float(h1 << 16), r3 = f3 - __uint_as_float(h1 & 0xFFFF0000u);
+    const unsigned m0 = cvt_pk_bf16(r0, r1), m1 = cvt_pk_bf16(r2, r3);
+    const float s0 = r0 - __uint_as_float(m0 << 16), s1 = r1 - __uint_as_float(m0 & 0xFFFF0000u);
+    const float s2 = r2 - __uint_as_float(m1 << 16), s3 = r3 - __uint_as_float(m1 & 0xFFFF0000u);
+    *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(dst + plane_bytes) = make_uint2(m0, m1);
+    *reinterpret_cast<uint2*>(dst + 2 * plane_bytes) = make_uint2(cvt_pk_bf16(s0, s1), cvt_pk_bf16(s2, s3));
+  };
+  auto store_x = [&](const u32x4 v, int f, int yy) {
+    if (f < C12_XW * 3) split_store(v, Xp + ((yy + 16) & 7) * C12_SLOT + f * 8, C12_ROWB);
+  };
+  auto store_g = [&](const u32x4 v, int f, int y) { split_store(v, Gp + (y & 1) * W12_GBUF + f * 8, W12_GPLANE); };
+  // prologue: input rows y0-3 .. y0+3 and gradient row y0, all 512 threads (216 / 512 float4 per row)
+  for (int yy = y0 - 3; yy <= y0 + 3; ++yy) store_x(load_x(tid, yy), tid, yy);
+  store_g(load_g(tid, y0), tid, y0);
+
+  if (wave == C12_WAVES) {
+    // ================= helper wave: input row y+4 and gradient row y+1 while the others work on row y
+    u32x4 nx[4], ng[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) nx[j] = load_x(lane + 64 * j, y0 + 4);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ng[j] = load_g(lane + 64 * j, y0 + 1);
+    __syncthreads();
+    for (int y = y0; y < y1; ++y) {
+      // every MFMA wave is past row y-1: input row y-4 (slot (y+4) & 7) and gradient buffer (y+1) & 1 are free
+#pragma unroll
+      for (int j = 0; j < 4; ++j) store_x(nx[j], lane + 64 * j, y + 4);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) store_g(ng[j], lane + 64 * j, y + 1);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) nx[j] = load_x(lane + 64 * j, y + 5);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ng[j] = load_g(lane + 64 * j, y + 2);
+      __syncthreads();
+    }
+    return;
+  }
+
+  // ================= MFMA waves: tap row th = wave.  A = g (M = 32 output channels), B = x (N = 96 columns (tw, ci)),
+  // K = 16 pixels.  Transposed reads: lane 4q+pp of 16-lane group g4 supplies the address of pixel 8 (g4 >> 1) + 4 j + q,
+  // columns 16 (g4 & 1) + 4 pp ..; it receives column 16 (g4 & 1) + (lane & 15), pixels 8 (g4 >> 1) + 4 j .. + 3.
+  const int th = wave, g4 = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+  const unsigned a_off = (unsigned)((8 * (g4 >> 1) + q) * 64 + (16 * (g4 & 1) + 4 * pp) * 2);
+  const unsigned b_off = (unsigned)((8 * (g4 >> 1) + q) * 24 + (16 * (g4 & 1) + 4 * pp) * 2);
+  auto frag = [&](const unsigned char* base, unsigned o0_, unsigned o1_) -> bf16x8_t {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + o0_));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + o1_));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+  };
+  f32x16 acc[3], acc2[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = acc2[t][e] = 0.f;
+  __syncthreads();
+  for (int y = y0; y < y1; ++y) {
+    const unsigned char* Xrow = Xp + ((y + th - 3 + 16) & 7) * C12_SLOT;
+    const unsigned char* Grow = Gp + (y & 1) * W12_GBUF;
+#pragma unroll
+    for (int ks = 0; ks < C12_CW / 16; ++ks) {
+      const unsigned ao = a_off + ks * 16 * 64, bo = b_off + ks * 16 * 24;
+      const bf16x8_t gh = frag(Grow, ao, ao + 4 * 64), gm = frag(Grow + W12_GPLANE, ao, ao + 4 * 64),
+                     gl = frag(Grow + 2 * W12_GPLANE, ao, ao + 4 * 64);
+      bf16x8_t xh[3], xm[3], xl[3];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const unsigned bt = bo + t * 64;
+        xh[t] = frag(Xrow, bt, bt + 4 * 24);
+        xm[t] = frag(Xrow + C12_ROWB, bt, bt + 4 * 24);
+        xl[t] = frag(Xrow + 2 * C12_ROWB, bt, bt + 4 * 24);
+      }
+      // piece pairs outermost (small terms first): consecutive MFMAs go to different accumulators
+#pragma unroll
+      for (int pc = 0; pc < 6; ++pc)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          const bf16x8_t a = pc == 0 ? gl : (pc == 2 || pc == 3) ? gm : gh;
+          const bf16x8_t b = pc == 1 ? xl[t] : (pc == 2 || pc == 4) ? xm[t] : xh[t];
+          if (pc < 5) acc2[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc2[t], 0, 0, 0);
+          else acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+  }
+  // D[o = 32 half + (e & 3) + 8 (e >> 2) + 4 (lane >> 5)][column j = 32 t + (lane & 31)] of tap row th; j = tw * 12 + ci < 84
+  float* __restrict__ dst = p.slab + (long)((n * R + r) * nch + ch) * p.O * p.ND;
+  const int lr = lane & 31, lh = lane >> 5;
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const int j = 32 * t + lr;
+    if (j >= 84) continue;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int o = 32 * half + (e & 3) + 8 * (e >> 2) + 4 * lh;
+      if (o < p.O) dst[(long)o * p.ND + th * 84 + j] = acc[t][e] + acc2[t][e];
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void pack_fwd_kernel(const float* __restrict__ w, float* __restrict__ out,
                                                        int O, int I, int IP, int taps) {
   const long total = (long)O * taps * IP;
@@ -2484,6 +2630,27 @@ static int halo7_plan(const FcdWgradDesc* d, int* rows, int* R, int* nch) {
   return splits <= 4096 ? (int)splits : 0;
 }
 
+// The halo form of the 7x7 weight gradient with 12 physical input channels under FCD_PREC_BF16X3
+// (wgrad7_c12_halo_x3_kernel): number of slabs, or 0.
+static int halo12w_plan(const FcdWgradDesc* d, int* rows, int* R, int* nch, int* halves) {
+  if (d->splitk > 0 || d->precision != FCD_PREC_BF16X3 || getenv("FCD_NO_WGRAD12")) return 0;
+  if (d->KH != 7 || d->KW != 7 || d->stride != 1 || d->pad != 3 || d->IP != 12 || d->O <= 16) return 0;
+  if (d->BH != d->GH || d->BW != d->GW) return 0;
+  const int c = fcd_cdiv(d->GW, C12_CW), hv = fcd_cdiv(d->O, 32);
+  const long base = (long)d->N * c * hv;
+  // about one workgroup per CU
+  long rr = (256 + base / 2) / base;
+  if (rr > d->GH / 8) rr = d->GH / 8;
+  if (rr < 1) rr = 1;
+  const int rw = fcd_cdiv(d->GH, (int)rr);
+  *rows = rw;
+  *R = fcd_cdiv(d->GH, rw);
+  *nch = c;
+  *halves = hv;
+  const long splits = (long)d->N * *R * c;
+  return splits <= 4096 ? (int)splits : 0;
+}
+
 static int wgrad_bm(const FcdWgradDesc* d) { return d->O <= 32 ? 32 : (d->O <= 64 ? 64 : (d->O <= 128 ? 128 : 256)); }
 
 static int resolve_wgrad_splitk(const FcdWgradDesc* d) {
@@ -2519,7 +2686,9 @@ static int validate_wgrad(const FcdWgradDesc* d) {
 extern "C" size_t fcd_wgrad_workspace_bytes(const FcdWgradDesc* d) {
   if (!d || d->O <= 0 || d->IP <= 0 || d->KH <= 0 || d->KW <= 0) return 0;
   int rows, R, nch;
-  const int halo = halo7_plan(d, &rows, &R, &nch);
+  int halo = halo7_plan(d, &rows, &R, &nch);
+  int halves;
+  if (!halo) halo = halo12w_plan(d, &rows, &R, &nch, &halves);
   return (size_t)(halo ? halo : resolve_wgrad_splitk(d)) * d->O * d->KH * d->KW * d->IP * sizeof(float);
 }
 
@@ -2566,6 +2735,13 @@ extern "C" int fcd_conv_wgrad(const FcdWgradDesc* d, const float* gsmall, const 
       hipLaunchKernelGGL(wgrad7_halo_kernel, grid, dim3(64 * H7_WAVES), 0, st, a, h_rows, h_R, h_nch,
                          (size_t)a.P * a.OP * 4, (size_t)a.N * a.BH * a.BW * a.IP * 4);
     }
+    rc = fcd_check_launch("conv_wgrad");
+  } else if (int hv = 0, slabs12 = halo12w_plan(d, &h_rows, &h_R, &h_nch, &hv); slabs12) {
+    a.splitk = slabs12;
+    dim3 grid(h_nch * h_R, d->N * hv);
+    note_kernel("wgrad7_c12_halo_x3_kernel");
+    hipLaunchKernelGGL(wgrad7_c12_halo_x3_kernel, grid, dim3(64 * (C12_WAVES + 1)), 0, st, a, h_rows, h_R, h_nch, hv,
+                       (size_t)a.P * a.OP * 4, (size_t)a.N * a.BH * a.BW * a.IP * 4);
     rc = fcd_check_launch("conv_wgrad");
   } else if (d->O <= 16 && d->precision != FCD_PREC_BF16) {   // exact fp32 16-row kernel, also under BF16X3
     a.tiles_m = 1; a.tiles_n = fcd_cdiv(a.ND, 128);

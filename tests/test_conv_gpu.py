@@ -368,3 +368,31 @@ def test_conv7_c12_halo_x3(dev, shape, monkeypatch):
     assert L.load().fcd_last_conv_kernel() == b"conv7_c12_halo_x3_kernel"
     gx_ref = torch.nn.grad.conv2d_input((n, 64, h, w), w2.double(), gy.double(), padding=3).permute(0, 2, 3, 1)
     assert relerr(gx, gx_ref) <= 1e-6
+
+
+@pytest.mark.parametrize("shape", [(64, 11, 2, 40, 24), (64, 10, 1, 9, 130), (40, 12, 3, 64, 64), (64, 11, 4, 128, 128), (17, 11, 2, 33, 70)])
+def test_wgrad7_c12_halo_x3(dev, shape, monkeypatch):
+    """Weight gradient of the generator's first layer (7x7, 11 -> 64, fixed_point_gan.py:45) under FCD_PREC_BF16X3: the
+    halo kernel (rows split once into bf16 planes in LDS, transposed reads along the pixel axis, the 7 taps of a tap
+    row as 84 consecutive values of a ring row) against torch in float64 and against the generic split-once kernel
+    (FCD_NO_WGRAD12=1); ragged widths / heights, 17 / 40 / 64 output channels, accumulation."""
+    from fcd_amd import _lib as L, ops
+    O, I, n, h, w = shape
+    g = ops.ConvGeom(O, I, 7, 1, 3)
+    gen = torch.Generator().manual_seed(7)
+    x = torch.randn(n, I, h, w, generator=gen)
+    gy = torch.randn(n, O, h, w, generator=gen)
+    xd, gd = to_nhwc(x, g.IP).to(dev), to_nhwc(gy, g.OP).to(dev)
+    ref = torch.nn.grad.conv2d_weight(x.double(), (O, I, 7, 7), gy.double(), stride=1, padding=3)
+    d = g.wgrad_desc(n, h, w, precision=2)
+    dw = ops.conv_wgrad(d, gd, xd)
+    assert L.load().fcd_last_conv_kernel() == b"wgrad7_c12_halo_x3_kernel"
+    assert relerr(dw.cpu(), ref) <= 1e-6
+    monkeypatch.setenv("FCD_NO_WGRAD12", "1")
+    generic = ops.conv_wgrad(d, gd, xd)
+    assert L.load().fcd_last_conv_kernel() != b"wgrad7_c12_halo_x3_kernel"
+    monkeypatch.delenv("FCD_NO_WGRAD12")
+    assert relerr(dw, generic) <= 1e-6
+    acc = torch.full_like(dw, 0.25)
+    ops.conv_wgrad(g.wgrad_desc(n, h, w, precision=2, accumulate=True), gd, xd, dw=acc)
+    assert relerr(acc.cpu() - 0.25, ref) <= 1e-5
