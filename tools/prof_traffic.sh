@@ -12,3 +12,6 @@ timeout -s KILL 90 rocprofv3 --output-format csv --pmc WRITE_SIZE -d $O/pmc_in_w
 timeout -s KILL 90 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $O/pmc_wgrad_f -o r -- python3 $R/tools/wgrad_once.py 2 32 > $O/pmc_wgrad_f.log 2>&1
 timeout -s KILL 90 rocprofv3 --output-format csv --pmc WRITE_SIZE -d $O/pmc_wgrad_w -o r -- python3 $R/tools/wgrad_once.py 2 32 > $O/pmc_wgrad_w.log 2>&1
 echo done
+# afterwards, in the repository (reads gpurun_out/, writes profiles/r2_traffic.json and the trimmed CSVs):
+#   python3 tools/pmc_traffic.py r2 resblock_conv_x3_b32=gpurun_out/pmc_conv_f,gpurun_out/pmc_conv_w \
+#       in_apply=gpurun_out/pmc_in_f,gpurun_out/pmc_in_w resblock_wgrad_x3_b32=gpurun_out/pmc_wgrad_f,gpurun_out/pmc_wgrad_w
