@@ -13,6 +13,7 @@
 // reproducible run to run.
 #include "fcd_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
@@ -227,7 +228,15 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 // layers; the B stage keeps its 32-row LDS slot, rows 16.. are loaded as zeros and never read.
 // BPRE (FCD_PREC_BF16X3 only): the weights arrive already split into three bf16 planes
 // ([plane][row][K], fcd_pack_weight_*_x3), so only the activation fragments are split in registers.
-template <int BM, int BN, int WM, int WN, int S, int PREC, bool N16 = false, bool BPRE = false>
+// AH ("A halo", BPRE only; 3x3, stride 1, pad 1, image width 32 or 64 so that the 256 rows of a tile are whole image
+// rows): the activation operand is not gathered per tap.  Per 32-channel slice the (R+2) x (W+2) halo region of
+// the tile is fetched ONCE (global -> registers, during the previous slice's taps), split ONCE into three bf16
+// planes [halo pixel][32 channels] in LDS, and the nine taps read their fragments from the planes at shifted pixel
+// addresses: no activation DMA, no split in the tap loop (a ninth of the split work, done once per workgroup
+// instead of once per wave), 16-byte chunk slot XOR ((pixel >> 2) & 3) keeps the shifted reads conflict-free.
+constexpr int ah_maxpx(int bm) { return bm == 256 ? 396 : 264; }   // (4 + 2) x 66 or 10 x 34 halo pixels; 128 rows: 4 x 66 or 6 x 34
+
+template <int BM, int BN, int WM, int WN, int S, int PREC, bool N16 = false, bool BPRE = false, bool AH = false>
 __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const GatherArgs p, const size_t in_bytes,
                                                                        const unsigned w_bytes) {
   static_assert(!N16 || (BN == 32 && WN == 1 && PREC == FCD_PREC_F32), "N16 shape");
@@ -240,12 +249,17 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
   // BPRE: a B row is 3 planes x 4 chunks (32 bf16 each); one DMA instruction ("unit") covers 16 rows of
   // a plane; units past 3*BN/16 (BN = 64: 12 units on 8 waves) are all-out-of-range dummies
   constexpr int BUNITS = 3 * BN / 16;
-  constexpr int AL = BM / RPI, BL = BPRE ? (BUNITS + NW - 1) / NW : BN / RPI;   // DMA instructions per wave per K-tile
-  constexpr int STAGE = BM * 8 + (BPRE ? BL * NW * 64 : BN * 8);   // float4 chunks per stage
+  constexpr int AL = AH ? 0 : BM / RPI, BL = BPRE ? (BUNITS + NW - 1) / NW : BN / RPI;   // DMA instructions per wave per K-tile
+  constexpr int AOFF = AH ? 0 : BM * 8;                            // float4 chunks of a stage's activation part
+  constexpr int STAGE = AOFF + (BPRE ? BL * NW * 64 : BN * 8);     // float4 chunks per stage
   static_assert((NW == 4 || NW == 8) && S >= 2 && BM % RPI == 0 && BN % RPI == 0 && TM >= 1 && TN >= 1, "shape");
+  static_assert(!AH || (BPRE && (BM == 256 || BM == 128) && NW == 8 && S == 3), "AH shape");
+  constexpr int AH_MAXPX = ah_maxpx(BM);
+  constexpr int AH_F4 = AH ? 3 * AH_MAXPX * 4 : 0;                 // three planes of 64 bytes per halo pixel
 
-  __shared__ float4 smem[S * STAGE + BM / 2];   // ring + rowoff (BM longs)
+  __shared__ float4 smem[S * STAGE + BM / 2 + AH_F4];   // ring + rowoff (BM longs) (+ the halo planes)
   long* rowoff = reinterpret_cast<long*>(smem + S * STAGE);
+  unsigned char* const Apl = reinterpret_cast<unsigned char*>(smem + S * STAGE + BM / 2);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -280,8 +294,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
   // holds chunk kc = slot ^ ((row>>1)&7): the swizzle lives in the SOURCE address.
   const int rl = 8 * wave + (lane >> 3);
   const int kc = (lane & 7) ^ ((rl >> 1) & 7);
-  int a_base[AL];          // byte offset of (n, ih0, iw0, 0); may be negative
-  unsigned a_mh[AL], a_mw[AL];
+  int a_base[AL > 0 ? AL : 1];          // byte offset of (n, ih0, iw0, 0); may be negative
+  unsigned a_mh[AL > 0 ? AL : 1], a_mw[AL > 0 ? AL : 1];
 #pragma unroll
   for (int i = 0; i < AL; ++i) {
     const int m = tm * BM + rl + RPI * i;
@@ -348,7 +362,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
     thc = th < 31 ? th : 31;
     live = alive ? 0xFFFFFFFFu : 0u;
     la = lds0 + (unsigned)(stage * STAGE + 8 * wave * 8) * 16u;   // A rows 8*wave.. of this stage
-    lb = la + BM * 8 * 16u;
+    lb = la + AOFF * 16u;
   };
   auto issue_one = [&](int q) {
     if (q < AL) {
@@ -359,7 +373,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
       if constexpr (BPRE) {
         // tile-level k (this lane's k minus its own A chunk), 2 bytes per element
         const unsigned voff = (b_base[q - AL] + (unsigned)((k - kc * 4) * 2)) | (OOB & ~live);
-        dma16(rw, voff, lds0 + (unsigned)(bstage * STAGE + BM * 8) * 16u + (unsigned)((wave + NW * (q - AL)) * 1024));
+        dma16(rw, voff, lds0 + (unsigned)(bstage * STAGE + AOFF) * 16u + (unsigned)((wave + NW * (q - AL)) * 1024));
       } else {
         const unsigned voff = (b_base[q - AL] + (unsigned)(k * 4)) | (OOB & ~live);   // invalid rows stay >= OOB
         dma16(rw, voff, lb + (q - AL) * (RPI * 8 * 16));
@@ -426,15 +440,70 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
     // all of tile `it`, whose stage takes the DMA of tile it+3, and tile it+1 has landed for the
     // split that runs under the second step's MFMAs.
     struct Pieces { bf16x8_t ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN]; };
-    auto load_split = [&](int stg, int s2, Pieces& P) {
+    // ---- AH: halo geometry, the staged next slice, the planes
+    const int W2 = p.GW + 2, APX = (BM / p.GW + 2) * W2, PB = APX * 64;      // halo row pitch, halo pixels, plane bytes
+    const int ah_y0 = (tm * BM - n0 * ghw) / p.GW;                          // first output row of this tile in its image
+    int hbase[TM];                                                          // halo pixel of this lane's rows at tap (0, 0)
+    constexpr int NLH = (AH_MAXPX * 8 + NT - 1) / NT;                       // float4 of a slice per thread (7)
+    u32x4 hst[AH ? NLH : 1];
+    __amdgpu_buffer_rsrc_t rinb = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(p.in)) + in_start, (short)0, (int)window_bytes(in_bytes, in_start), 0x00020000);
+    if constexpr (AH) {
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi) {
+        const int r = wm * WTM + mi * 32 + lr;
+        hbase[mi] = (r / p.GW) * W2 + r % p.GW;
+      }
+    }
+    // float4 f of a slice = halo pixel f >> 3, channels 4 (f & 7) .. of the slice
+    auto ah_load = [&](int cs) {
+#pragma unroll
+      for (int j = 0; j < NLH; ++j) {
+        const int f = tid + NT * j, hp = f >> 3, c4 = f & 7;
+        const int hy = hp / W2, hx = hp - hy * W2, iy = ah_y0 - 1 + hy, ix = hx - 1;
+        const unsigned okm = 0u - (unsigned)((int)(hp < APX) & (int)(cs * 32 < p.Cin) & (int)(iy >= 0) & (int)(iy < p.IH) &
+                                             (int)(ix >= 0) & (int)(ix < p.IW));
+        const unsigned voff = ((unsigned)(((iy * p.IW + ix) * p.Cin + cs * 32 + c4 * 4) * 4) & okm) | (OOB & ~okm);
+        hst[j] = __builtin_amdgcn_raw_buffer_load_b128(rinb, (int)voff, 0, 0);
+      }
+    };
+    auto ah_store = [&]() {
+#pragma unroll
+      for (int j = 0; j < NLH; ++j) {
+        const int f = tid + NT * j, hp = f >> 3, c4 = f & 7;
+        if (hp >= APX) continue;
+        unsigned char* dst = Apl + hp * 64 + (((c4 >> 1) ^ ((hp >> 2) & 3)) << 4) + 8 * (c4 & 1);
+        const u32x4 v = hst[j];
+        const float f0 = __uint_as_float(v.x), f1 = __uint_as_float(v.y), f2 = __uint_as_float(v.z), f3 = __uint_as_float(v.w);
+        const unsigned h0 = cvt_pk_bf16(f0, f1), h1 = cvt_pk_bf16(f2, f3);
+        const float r0 = f0 - __uint_as_float(h0 << 16), r1 = f1 - __uint_as_float(h0 & 0xFFFF0000u);
+        const float r2 = f2 - __uint_as_float(h1 << 16), r3 = f3 - __uint_as_float(h1 & 0xFFFF0000u);
+        const unsigned m0 = cvt_pk_bf16(r0, r1), m1 = cvt_pk_bf16(r2, r3);
+        const float s0 = r0 - __uint_as_float(m0 << 16), s1 = r1 - __uint_as_float(m0 & 0xFFFF0000u);
+        const float s2 = r2 - __uint_as_float(m1 << 16), s3 = r3 - __uint_as_float(m1 & 0xFFFF0000u);
+        *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(dst + PB) = make_uint2(m0, m1);
+        *reinterpret_cast<uint2*>(dst + 2 * PB) = make_uint2(cvt_pk_bf16(s0, s1), cvt_pk_bf16(s2, s3));
+      }
+    };
+    // toff: halo-pixel offset th * W2 + tw of the tap the tile belongs to (AH only)
+    auto load_split = [&](int stg, int s2, Pieces& P, int toff) {
       const float4* As = smem + stg * STAGE;
-      const float4* Bs = As + BM * 8;
+      const float4* Bs = As + AOFF;
       const int c0 = 4 * s2 + 2 * lh;
 #pragma unroll
       for (int mi = 0; mi < TM; ++mi) {
-        const int r = wm * WTM + mi * 32 + lr, sw = (r >> 1) & 7;
-        const float4 lo = As[r * 8 + (c0 ^ sw)], hi = As[r * 8 + ((c0 + 1) ^ sw)];
-        split3(f32x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w}, P.ah[mi], P.am[mi], P.al[mi]);
+        if constexpr (AH) {
+          const int hp = hbase[mi] + toff;
+          const unsigned char* a = Apl + hp * 64 + (((2 * s2 + lh) ^ ((hp >> 2) & 3)) << 4);
+          P.ah[mi] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(a));
+          P.am[mi] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(a + PB));
+          P.al[mi] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(a + 2 * PB));
+        } else {
+          const int r = wm * WTM + mi * 32 + lr, sw = (r >> 1) & 7;
+          const float4 lo = As[r * 8 + (c0 ^ sw)], hi = As[r * 8 + ((c0 + 1) ^ sw)];
+          split3(f32x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w}, P.ah[mi], P.am[mi], P.al[mi]);
+        }
       }
 #pragma unroll
       for (int ni = 0; ni < TN; ++ni) {
@@ -469,6 +538,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
             }
           }
     };
+    if constexpr (AH) {
+      ah_load(0);
+      ah_store();
+      ah_load(1);
+    }
 #pragma unroll
     for (int s = 0; s < S; ++s) {
       issue_prepare(s, s < nk);
@@ -478,20 +552,61 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
     }
     Pieces P0, P1;
     wait_vmcnt<(S - 1) * ND>();
+    if constexpr (AH) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    load_split(0, 0, P0);
+    load_split(0, 0, P0, 0);
     int stage = 0;
+    if constexpr (AH) {
+      // nk = 9 taps x Cin / 32 slices; taps 0 .. 7 of a slice run the plain body (one basic block), the last tap
+      // carries the slice change between its two k16-steps
+      auto body = [&](auto bnd, int it, int toff, int toff_next, int cs) {
+        const int next = stage == S - 1 ? 0 : stage + 1;
+        load_split(stage, 1, P1, toff);
+        mfma_phase(P0, false);
+        wait_vmcnt<(S - 2) * ND>();
+        __builtin_amdgcn_s_barrier();     // every wave is done reading tile it -- and, at the last tap, the planes
+        issue_prepare(stage, it + S < nk);
+        if constexpr (decltype(bnd)::value) {
+          mfma_phase(P1, true);
+          ah_store();                     // slice cs+1 (staged since the last slice change) -> planes
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          ah_load(cs + 2);                // zeros past the last slice
+          load_split(next, 0, P0, toff_next);
+        } else {
+          load_split(next, 0, P0, toff_next);
+          mfma_phase(P1, true);
+        }
+        issue_advance();
+        stage = next;
+      };
+      int it = 0;
+      for (int cs = 0; cs * 32 < p.Cin; ++cs) {
+        int toff = 0, twc = 0;
+        for (int t9 = 0; t9 < 8; ++t9) {
+          const bool wrap = twc == 2;
+          const int toff_next = toff + (wrap ? W2 - 2 : 1);
+          body(std::false_type{}, it, toff, toff_next, cs);
+          toff = toff_next;
+          twc = wrap ? 0 : twc + 1;
+          ++it;
+        }
+        body(std::true_type{}, it, toff, 0, cs);
+        ++it;
+      }
+    } else {
     for (int it = 0; it < nk; ++it) {
       const int next = stage == S - 1 ? 0 : stage + 1;
-      load_split(stage, 1, P1);         // VALU under ...
+      load_split(stage, 1, P1, 0);      // VALU under ...
       mfma_phase(P0, false);            // ... the MFMAs of step 0
       wait_vmcnt<(S - 2) * ND>();       // tile it+1 landed (S = 3: tile it+2 may fly)
       __builtin_amdgcn_s_barrier();     // every wave is done reading tile it
       issue_prepare(stage, it + S < nk);
-      load_split(next, 0, P0);          // first step of tile it+1 (zeros past the end) under ...
+      load_split(next, 0, P0, 0);       // first step of tile it+1 (zeros past the end) under ...
       mfma_phase(P1, true);             // ... the MFMAs of step 1, with the DMA of tile it+3 among them
       issue_advance();
       stage = next;
+    }
     }
     wait_vmcnt<0>();
   } else {
@@ -511,7 +626,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
     __builtin_amdgcn_s_barrier();
     issue_prepare(nstage, it + S - 1 < nk);
     const float4* As = smem + stage * STAGE;
-    const float4* Bs = As + BM * 8;
+    const float4* Bs = As + AOFF;
     if constexpr (N16) {
       // 16x16x4 MFMAs: lane group g = lane>>4 of round j reads chunk 4j+g; element e of the
       // chunk feeds MFMA e (the k permutation is the same for A and B)
@@ -2410,6 +2525,20 @@ bool gather_big_tile(const FcdConvDesc* d) {
   return (long)fcd_cdiv(M, 256) * fcd_cdiv(d->Cout, bn) * d->nphase >= 256;
 }
 
+// The A-halo form of the pre-split 256x128 / 128x128 kernels (template flag AH): 3x3, stride 1, pad 1, one phase, no
+// split-K, image width 32 or 64 and a height that keeps the tiles (`rows` output rows) inside one image.
+bool gather_ahalo(const FcdConvDesc* d, int rows) {
+  if (getenv("FCD_NO_HALO3")) return false;
+  if (!wants_split_weights(d) || resolve_splitk(d) != 1) return false;
+  int bm, bn;
+  gather_tile(d, bm, bn);
+  if (bn != 128 || d->KH != 3 || d->KW != 3 || d->nphase != 1 || d->istride != 1 || d->ostride != 1) return false;
+  if (d->pad_h[0] != 1 || d->pad_w[0] != 1 || d->ooff_h[0] || d->ooff_w[0]) return false;
+  if (d->GH != d->IH || d->GW != d->IW || d->OH != d->GH || d->OW != d->GW) return false;
+  if (d->GW != 32 && d->GW != 64) return false;
+  return d->GH % (rows / d->GW) == 0;
+}
+
 // The halo form of the 7x7, 64 -> <= 16 channel convolution (conv7_halo_kernel): rows per workgroup, or 0.
 int halo7_fwd_rows(const FcdConvDesc* d, const GatherArgs& a) {
   if (d->precision == FCD_PREC_BF16 || d->KH != 7 || d->KW != 7 || d->nphase != 1 || d->istride != 1 || d->ostride != 1) return 0;
@@ -2478,12 +2607,20 @@ int run_gather(const FcdConvDesc* d, GatherArgs& a, hipStream_t st) {
       grid = dim3(a.tiles_m * a.tiles_n, a.nphase * a.splitk);
       note_kernel(bn == 128 ? "conv_gather_dma_kernel<256, 128, 4, 2, 2, 2, false, true>"
                             : "conv_gather_dma_kernel<256, 64, 8, 1, 3, 2, false, true>");
-      if (bn == 128)
+      if (gather_ahalo(d, 256)) {
+        note_kernel("conv_gather_dma_kernel<256, 128, 4, 2, 3, 2, false, true, true>");
+        hipLaunchKernelGGL((conv_gather_dma_kernel<256, 128, 4, 2, 3, FCD_PREC_BF16X3, false, true, true>), grid, dim3(512), 0, st,
+                           a, in_bytes, w_bytes);
+      } else if (bn == 128)
         hipLaunchKernelGGL((conv_gather_dma_kernel<256, 128, 4, 2, 2, FCD_PREC_BF16X3, false, true>), grid, dim3(512), 0, st, a,
                            in_bytes, w_bytes);
       else
         hipLaunchKernelGGL((conv_gather_dma_kernel<256, 64, 8, 1, 3, FCD_PREC_BF16X3, false, true>), grid, dim3(512), 0, st, a,
                            in_bytes, w_bytes);
+    } else if (bn == 128 && gather_ahalo(d, 128)) {
+      note_kernel("conv_gather_dma_kernel<128, 128, 4, 2, 3, 2, false, true, true>");
+      hipLaunchKernelGGL((conv_gather_dma_kernel<128, 128, 4, 2, 3, FCD_PREC_BF16X3, false, true, true>), grid, dim3(512), 0, st, a,
+                         in_bytes, w_bytes);
     } else if (bn == 128) {
       note_kernel("conv_gather_dma_kernel<128, 128, 4, 2, 3, 2, false, true>");
       hipLaunchKernelGGL((conv_gather_dma_kernel<128, 128, 4, 2, 3, FCD_PREC_BF16X3, false, true>), grid, dim3(512), 0, st, a,

@@ -396,3 +396,60 @@ def test_wgrad7_c12_halo_x3(dev, shape, monkeypatch):
     acc = torch.full_like(dw, 0.25)
     ops.conv_wgrad(g.wgrad_desc(n, h, w, precision=2, accumulate=True), gd, xd, dw=acc)
     assert relerr(acc.cpu() - 0.25, ref) <= 1e-5
+
+
+# (O, I, N, H, W, form): 3x3, stride 1, pad 1 with image width 32 / 64 and enough tiles for no split-K
+AHALO_GEOMS = [
+    (256, 256, 32, 32, 32, "fwd"),      # residual-block conv, paired G step: 256-row tiles
+    (256, 256, 16, 32, 32, "adj"),      # its data gradient at 16 samples: 128-row tiles
+    (128, 96, 9, 64, 64, "fwd"),        # 64-wide images, 96 input channels (3 slices), tiles of 2 / 4 image rows
+    (64, 192, 25, 16, 32, "adj"),       # ragged output-channel tile (192 = 128 + 64), short images
+]
+
+
+@pytest.mark.parametrize("geom", AHALO_GEOMS)
+def test_gather_a_halo_equals_per_tap_gather(dev, geom, monkeypatch):
+    """FCD_PREC_BF16X3 3x3 convolutions: the A-halo form (the tile's halo region split once per 32-channel slice into
+    bf16 planes in LDS, nine taps read at shifted pixel addresses; template flag AH) forms the same products in the
+    same order as the per-tap gather form (FCD_NO_HALO3=1): identical bits, with bias / activation, mask / residual
+    epilogues and the fused InstanceNorm statistics; and within 1e-5 of torch."""
+    from fcd_amd import _lib as L, ops
+    O, I, N, H, W, form = geom
+    g = ops.ConvGeom(O, I, 3, 1, 1)
+    gen = torch.Generator().manual_seed(9)
+    wt = torch.randn(O, I, 3, 3, generator=gen) / (3 * I ** 0.5)
+    if form == "fwd":
+        x = torch.randn(N, I, H, W, generator=gen)
+        b = torch.randn(O, generator=gen)
+        d = g.fwd_desc(N, H, W, precision=2, act_slope=0.01)
+        wp = ops.pack_weight_fwd_x3(wt.to(dev), g)
+        xd = to_nhwc(x, g.IP).to(dev)
+        run = lambda: ops.conv_gather(d, xd, wp, bias=b.to(dev))
+        ref = F.leaky_relu(F.conv2d(x.double(), wt.double(), b.double(), 1, 1), 0.01)
+        cref = O
+        d0 = g.fwd_desc(N, H, W, precision=2)
+        stats = lambda: ops.conv_gather_stats(d0, xd, wp, want_var=True)
+    else:
+        gy = torch.randn(N, O, H, W, generator=gen)
+        mask = torch.randn(N, I, H, W, generator=gen)
+        res = torch.randn(N, I, H, W, generator=gen)
+        d = g.adj_desc(N, H, W, precision=2, mask_slope=0.01)
+        wp = ops.pack_weight_adj_x3(wt.to(dev), g)
+        gd, md, rd = to_nhwc(gy, g.OP).to(dev), to_nhwc(mask, g.IP).to(dev), to_nhwc(res, g.IP).to(dev)
+        run = lambda: ops.conv_gather(d, gd, wp, mask=md, residual=rd)
+        ref = F.conv_transpose2d(gy.double(), wt.double(), None, 1, 1) * torch.where(mask > 0, 1.0, 0.01) + res
+        cref = I
+        stats = None
+    new = run().clone()
+    assert L.load().fcd_last_conv_kernel().endswith(b"true, true>")
+    st_new = [t.clone() for t in stats()] if stats else None
+    monkeypatch.setenv("FCD_NO_HALO3", "1")
+    old = run().clone()
+    assert not L.load().fcd_last_conv_kernel().endswith(b"true, true>")
+    st_old = [t.clone() for t in stats()] if stats else None
+    monkeypatch.delenv("FCD_NO_HALO3")
+    assert torch.equal(new, old)
+    if stats:
+        for a, b2 in zip(st_new, st_old):
+            assert torch.equal(a, b2)
+    assert relerr(from_nhwc(new.cpu(), cref).double(), ref) <= 1e-5
