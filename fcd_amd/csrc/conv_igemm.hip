@@ -2125,6 +2125,178 @@ __global__ __launch_bounds__(64 * (C12_WAVES + 1)) void conv7_c12_halo_x3_kernel
   __syncthreads();
 }
 
+// Weight gradient of a 3x3, stride-1, pad-1 convolution on 32-pixel-wide images (the residual blocks), FCD_PREC_BF16X3,
+// halo form.  The generic split-once kernel gives every (tap, 128 channels) column tile a workgroup of its own: the
+// gradient tile is fetched and split by all 18 of them, the input tile gathered per tap.  Here a workgroup owns
+// (64 output channels, 64 input channels, a range of whole images) and ALL NINE taps: per image row (= one 32-pixel K
+// step) two helper waves fetch the gradient row and the next input row once, split them once into three bf16
+// planes [pixel][64 channels] in LDS (input: 4-slot ring of 34-pixel rows, zero rows above / below the image;
+// gradient: two buffers); the eight MFMA waves (2 halves of the output channels x 4 quarters of the input channels)
+// read their fragments with ds_read_b64_tr_b16 (K = pixel axis) -- a tap is a row of the ring and a shift of the
+// pixel -- and run 16x16x32 bf16 MFMAs into 2 x 9 accumulator tiles.  32-byte channel blocks are XOR-swizzled with
+// pixel bits 1 and 3 so that the eight pixel rows a read's 32 lanes fetch fall into eight different bank groups.
+constexpr int W3_XW = 34;                         // pixels per ring row (32 + 2 halo)
+constexpr int W3_XPLANE = W3_XW * 128;            // bytes: [pixel][64 channels] bf16
+constexpr int W3_XSLOT = 3 * W3_XPLANE;
+constexpr int W3_GPLANE = 32 * 128;
+constexpr int W3_GBUF = 3 * W3_GPLANE;
+constexpr int W3_WAVES = 8;                       // MFMA waves; two more load / split
+__device__ __forceinline__ unsigned w3_off(int px, int col) {      // col: channel, a multiple of 4
+  return (unsigned)(px * 128 + (((col >> 4) ^ (((px >> 1) & 1) | (((px >> 3) & 1) << 1))) << 5) + (col & 15) * 2);
+}
+
+__global__ __launch_bounds__(64 * W3_WAVES) void wgrad3_halo_x3_kernel(const WgradArgs p, const int ipS, const int ncb,
+                                                                             const size_t gs_bytes, const size_t xb_bytes) {
+  __shared__ __attribute__((aligned(16))) unsigned char Xp[4 * W3_XSLOT];
+  __shared__ __attribute__((aligned(16))) unsigned char Gp[2 * W3_GBUF];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cb = blockIdx.x % ncb, ob = blockIdx.x / ncb, split = blockIdx.y;
+  const int n_begin = split * ipS, n_end = min(p.N, n_begin + ipS);
+  const int GH = p.GH;
+  // operand windows: from this split's first image on
+  const size_t gs_start = (size_t)n_begin * GH * 32 * p.OP * 4, xb_start = (size_t)n_begin * GH * 32 * p.IP * 4;
+  __amdgpu_buffer_rsrc_t rgs = __builtin_amdgcn_make_buffer_rsrc((char*)p.gs + gs_start, (short)0,
+                                                                 (int)window_bytes(gs_bytes, gs_start), 0x00020000);
+  __amdgpu_buffer_rsrc_t rxb = __builtin_amdgcn_make_buffer_rsrc((char*)p.xb + xb_start, (short)0,
+                                                                 (int)window_bytes(xb_bytes, xb_start), 0x00020000);
+
+  // float4 f of an input row = pixel f >> 4 (of 34), channels 64 cb + 4 (f & 15) ..; of a gradient row = pixel f >> 4
+  // (of 32), output channels 64 ob + 4 (f & 15) ..   (img: image index relative to n_begin)
+  auto load_x = [&](int f, int img, int yy) -> u32x4 {
+    const int px = f >> 4, c4 = f & 15, gx = px - 1;
+    const unsigned okm = 0u - (unsigned)((int)(px < W3_XW) & (int)(yy >= 0) & (int)(yy < GH) & (int)(gx >= 0) & (int)(gx < 32));
+    const unsigned voff = ((unsigned)((((img * GH + yy) * 32 + gx) * p.IP + cb * 64 + c4 * 4) * 4) & okm) | (OOB & ~okm);
+    return __builtin_amdgcn_raw_buffer_load_b128(rxb, (int)voff, 0, 0);
+  };
+  auto load_g = [&](int f, int img, int y) -> u32x4 {
+    const int px = f >> 4, c = ob * 64 + 4 * (f & 15);
+    const unsigned okm = 0u - (unsigned)((int)(y < GH) & (int)(c < p.OP));
+    const unsigned voff = ((unsigned)((((img * GH + y) * 32 + px) * p.OP + c) * 4) & okm) | (OOB & ~okm);
+    return __builtin_amdgcn_raw_buffer_load_b128(rgs, (int)voff, 0, 0);
+  };
+  auto split_store = [&](const u32x4 v, unsigned char* dst, int plane_bytes) {
+    const float f0 = __uint_as_float(v.x), f1 = __uint_as_float(v.y), f2 = __uint_as_float(v.z), f3 = __uint_as_float(v.w);
+    const unsigned h0 = cvt_pk_bf16(f0, f1), h1 = cvt_pk_bf16(f2, f3);
+    const float r0 = f0 - __uint_as_float(h0 << 16), r1 = f1 - __uint_as_float(h0 & 0xFFFF0000u);
+    const float r2 = f2 - __uint_as_float(h1 << 16), r3 = f3 - __uint_as_float(h1 & 0xFFFF0000u);
+    const unsigned m0 = cvt_pk_bf16(r0, r1), m1 = cvt_pk_bf16(r2, r3);
+    const float s0 = r0 - __uint_as_float(m0 << 16), s1 = r1 - __uint_as_float(m0 & 0xFFFF0000u);
+    const float s2 = r2 - __uint_as_float(m1 << 16), s3 = r3 - __uint_as_float(m1 & 0xFFFF0000u);
+    *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(dst + plane_bytes) = make_uint2(m0, m1);
+    *reinterpret_cast<uint2*>(dst + 2 * plane_bytes) = make_uint2(cvt_pk_bf16(s0, s1), cvt_pk_bf16(s2, s3));
+  };
+  // input row yy lives in ring slot (yy + 1) & 3
+  auto store_x = [&](const u32x4 v, int f, int yy) {
+    if (f < W3_XW * 16) split_store(v, Xp + ((yy + 1) & 3) * W3_XSLOT + w3_off(f >> 4, 4 * (f & 15)), W3_XPLANE);
+  };
+  auto store_g = [&](const u32x4 v, int f, int y) { split_store(v, Gp + (y & 1) * W3_GBUF + w3_off(f >> 4, 4 * (f & 15)), W3_GPLANE); };
+
+  // MFMA-wave roles: lane (c = lane & 15, kq = lane >> 4) receives channel c of its tile, pixels 8 kq + 4 j .. + 3 from
+  // read j; it supplies the address of pixel 8 kq + 4 j + (c >> 2), channels 4 (c & 3) .. of the tile
+  const int c16 = lane & 15, kq = lane >> 4, q = c16 >> 2, pp = c16 & 3;
+  const int oh = wave & 1, cq = (wave >> 1) & 3;
+  auto frag = [&](const unsigned char* base, int px, int col) -> bf16x8_t {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + w3_off(px, col)));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + w3_off(px + 4, col)));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+  };
+  f32x4 acc[2][9], acc2[2][9];
+#pragma unroll
+  for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[ot][t] = acc2[ot][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // the 544 + 512 float4 of (input row, gradient row) are dealt to the 512 threads: input item tid, gradient item tid,
+  // and the last 32 input items to the first 32 threads (each load keeps one buffer descriptor)
+  constexpr int NX4 = W3_XW * 16;
+  u32x4 st[3];
+  auto load_items = [&](int img, int yx, int yg) {
+    st[0] = load_x(tid, img, yx);
+    st[1] = load_g(tid, img, yg);
+    if (wave == 0) st[2] = load_x(512 + lane, img, yx);       // (lanes 32 .. 63: masked, zeros)
+  };
+  auto store_items = [&](int yx, int yg, bool with_g) {
+    store_x(st[0], tid, yx);
+    if (with_g) store_g(st[1], tid, yg);
+    if (wave == 0 && lane < NX4 - 512) store_x(st[2], 512 + lane, yx);
+  };
+  for (int n = n_begin; n < n_end; ++n) {
+    const int img = n - n_begin;
+    // prologue of an image: input rows -1 (zeros), 0, 1 and gradient row 0; every wave is past the last step of the
+    // previous image (its closing barrier)
+    load_items(img, -1, 0);
+    store_items(-1, 0, true);
+    load_items(img, 0, 1);
+    store_items(0, 1, true);
+    load_items(img, 1, GH);
+    store_items(1, 0, false);
+    load_items(img, 2, GH);
+    store_items(2, 0, false);
+    load_items(img, 3, 2);             // staged: input row 3, gradient row 2
+    __syncthreads();
+    for (int y = 0; y < GH; ++y) {
+      const unsigned char* Grow = Gp + (y & 1) * W3_GBUF;
+      const int px = 8 * kq + q, xcol = 16 * cq + 4 * pp;
+      bf16x8_t gh[2], gm[2], gl[2];
+#pragma unroll
+      for (int ot = 0; ot < 2; ++ot) {
+        const int col = 16 * (2 * oh + ot) + 4 * pp;
+        gh[ot] = frag(Grow, px, col);
+        gm[ot] = frag(Grow + W3_GPLANE, px, col);
+        gl[ot] = frag(Grow + 2 * W3_GPLANE, px, col);
+      }
+      // one tap ahead: the fragments of tap t+1 are in flight under the MFMAs of tap t
+      bf16x8_t xh[2], xm[2], xl[2];
+      auto load_tap = [&](int t, int b) {
+        const unsigned char* Xrow = Xp + ((y + t / 3) & 3) * W3_XSLOT;      // input row y + th - 1
+        xh[b] = frag(Xrow, px + t % 3, xcol);
+        xm[b] = frag(Xrow + W3_XPLANE, px + t % 3, xcol);
+        xl[b] = frag(Xrow + 2 * W3_XPLANE, px + t % 3, xcol);
+      };
+      load_tap(0, 0);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        if (t + 1 < 9) load_tap(t + 1, (t + 1) & 1);
+        if (t == 3) {
+          // Every wave has read input row y-1 (taps 0 .. 2) and the gradient row: their places take the staged input
+          // row y+3 and gradient row y+2, which the NEXT step's barrier publishes for step y+2.  The barrier sits in
+          // the middle of the step, with the next tap's fragments already loaded, so no wave restarts cold after it.
+          __syncthreads();
+          store_items(y + 3, y + 2, true);
+          load_items(img, y + 4, y + 3);
+        }
+        // piece pairs outermost (small terms first): consecutive MFMAs go to different accumulators
+#pragma unroll
+        for (int pc = 0; pc < 6; ++pc)
+#pragma unroll
+          for (int ot = 0; ot < 2; ++ot) {
+            const bf16x8_t a = pc == 0 ? gl[ot] : (pc == 2 || pc == 3) ? gm[ot] : gh[ot];
+            const bf16x8_t b = pc == 1 ? xl[t & 1] : (pc == 2 || pc == 4) ? xm[t & 1] : xh[t & 1];
+            if (pc < 5) acc2[ot][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc2[ot][t], 0, 0, 0);
+            else acc[ot][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[ot][t], 0, 0, 0);
+          }
+      }
+    }
+    __syncthreads();                   // the last step's reads are done before the next image's prologue stores
+  }
+  // D[o = 64 ob + 16 (2 oh + ot) + 4 kq + e][ci = 64 cb + 16 cq + c16] of tap t
+  float* __restrict__ dst = p.slab + (long)split * p.O * p.ND;
+#pragma unroll
+  for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int col = t * p.IP + cb * 64 + cq * 16 + c16;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int o = ob * 64 + 16 * (2 * oh + ot) + 4 * kq + e;
+        if (o < p.O) dst[(long)o * p.ND + col] = acc[ot][t][e] + acc2[ot][t][e];
+      }
+    }
+}
+
 // Weight gradient of the 7x7, stride-1, pad-3 convolution from 12 physical channels (the generator's first layer),
 // FCD_PREC_BF16X3, halo form.  The generic kernel gathers the 588 (tap, channel) columns of every pixel row from
 // global memory for each of its 5 column tiles and splits them in every workgroup.  Here a workgroup owns (image,
@@ -2788,6 +2960,20 @@ static int halo12w_plan(const FcdWgradDesc* d, int* rows, int* R, int* nch, int*
   return splits <= 4096 ? (int)splits : 0;
 }
 
+// The halo form of the 3x3 weight gradient on 32-pixel-wide images under FCD_PREC_BF16X3 (wgrad3_halo_x3_kernel):
+// number of slabs (= splits over whole images), or 0; *ipS = images per split.
+static int halo3w_plan(const FcdWgradDesc* d, int* ipS) {
+  if (d->splitk > 0 || d->precision != FCD_PREC_BF16X3 || getenv("FCD_NO_WGRAD3")) return 0;
+  if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->GW != 32 || d->BW != 32 || d->BH != d->GH) return 0;
+  if (d->IP % 64 != 0 || d->OP % 64 != 0 || d->O <= 32 || d->GH < 2) return 0;
+  const long blocks = (long)(d->OP / 64) * (d->IP / 64);
+  if (blocks * d->N < 192) return 0;                       // too few workgroups: the split-K kernel fills the chip better
+  long per = ((long)d->N * blocks + 128) / 256;            // images per split: about one workgroup per CU
+  if (per < 1) per = 1;
+  *ipS = (int)per;
+  return fcd_cdiv(d->N, (int)per);
+}
+
 static int wgrad_bm(const FcdWgradDesc* d) { return d->O <= 32 ? 32 : (d->O <= 64 ? 64 : (d->O <= 128 ? 128 : 256)); }
 
 static int resolve_wgrad_splitk(const FcdWgradDesc* d) {
@@ -2826,6 +3012,7 @@ extern "C" size_t fcd_wgrad_workspace_bytes(const FcdWgradDesc* d) {
   int halo = halo7_plan(d, &rows, &R, &nch);
   int halves;
   if (!halo) halo = halo12w_plan(d, &rows, &R, &nch, &halves);
+  if (!halo) halo = halo3w_plan(d, &rows);
   return (size_t)(halo ? halo : resolve_wgrad_splitk(d)) * d->O * d->KH * d->KW * d->IP * sizeof(float);
 }
 
@@ -2872,6 +3059,14 @@ extern "C" int fcd_conv_wgrad(const FcdWgradDesc* d, const float* gsmall, const 
       hipLaunchKernelGGL(wgrad7_halo_kernel, grid, dim3(64 * H7_WAVES), 0, st, a, h_rows, h_R, h_nch,
                          (size_t)a.P * a.OP * 4, (size_t)a.N * a.BH * a.BW * a.IP * 4);
     }
+    rc = fcd_check_launch("conv_wgrad");
+  } else if (int ipS = 0, slabs3 = halo3w_plan(d, &ipS); slabs3) {
+    a.splitk = slabs3;
+    const int ncb = d->IP / 64;
+    dim3 grid((d->OP / 64) * ncb, slabs3);
+    note_kernel("wgrad3_halo_x3_kernel");
+    hipLaunchKernelGGL(wgrad3_halo_x3_kernel, grid, dim3(64 * W3_WAVES), 0, st, a, ipS, ncb,
+                       (size_t)a.P * a.OP * 4, (size_t)a.N * a.BH * a.BW * a.IP * 4);
     rc = fcd_check_launch("conv_wgrad");
   } else if (int hv = 0, slabs12 = halo12w_plan(d, &h_rows, &h_R, &h_nch, &hv); slabs12) {
     a.splitk = slabs12;

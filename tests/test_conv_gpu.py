@@ -453,3 +453,32 @@ def test_gather_a_halo_equals_per_tap_gather(dev, geom, monkeypatch):
         for a, b2 in zip(st_new, st_old):
             assert torch.equal(a, b2)
     assert relerr(from_nhwc(new.cpu(), cref).double(), ref) <= 1e-5
+
+
+@pytest.mark.parametrize("shape", [(256, 256, 16, 4), (128, 192, 40, 5), (64, 64, 200, 2), (254, 128, 30, 3), (256, 256, 32, 32)])
+def test_wgrad3_halo_x3(dev, shape, monkeypatch):
+    """Weight gradient of the residual blocks' 3x3 convolutions (fixed_point_gan.py:26-31) on 32-pixel-wide images under
+    FCD_PREC_BF16X3: the halo kernel (a workgroup owns 64 x 64 channels and all nine taps; rows split once into bf16
+    planes, taps = ring rows and pixel shifts of transposed reads) against torch in float64 and against the generic
+    split-once kernel (FCD_NO_WGRAD3=1); several images per split, ragged output channels, accumulation."""
+    from fcd_amd import _lib as L, ops
+    O, I, n, h = shape
+    g = ops.ConvGeom(O, I, 3, 1, 1)
+    gen = torch.Generator().manual_seed(13)
+    x = torch.randn(n, I, h, 32, generator=gen)
+    gy = torch.randn(n, O, h, 32, generator=gen)
+    xd, gd = to_nhwc(x, g.IP).to(dev), to_nhwc(gy, g.OP).to(dev)
+    d = g.wgrad_desc(n, h, 32, precision=2)
+    dw = ops.conv_wgrad(d, gd, xd)
+    assert L.load().fcd_last_conv_kernel() == b"wgrad3_halo_x3_kernel"
+    monkeypatch.setenv("FCD_NO_WGRAD3", "1")
+    generic = ops.conv_wgrad(d, gd, xd)
+    assert L.load().fcd_last_conv_kernel() != b"wgrad3_halo_x3_kernel"
+    monkeypatch.delenv("FCD_NO_WGRAD3")
+    assert relerr(dw, generic) <= 2e-6
+    if n * h <= 200:
+        ref = torch.nn.grad.conv2d_weight(x.double(), (O, I, 3, 3), gy.double(), stride=1, padding=1)
+        assert relerr(dw.cpu(), ref) <= 1e-6
+        acc = torch.full_like(dw, 0.25)
+        ops.conv_wgrad(g.wgrad_desc(n, h, 32, precision=2, accumulate=True), gd, xd, dw=acc)
+        assert relerr(acc.cpu() - 0.25, ref) <= 1e-5
