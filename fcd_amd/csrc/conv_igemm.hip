@@ -2151,7 +2151,11 @@ __global__ __launch_bounds__(64 * W3_WAVES) void wgrad3_halo_x3_kernel(const Wgr
   __shared__ __attribute__((aligned(16))) unsigned char Gp[2 * W3_GBUF];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int cb = blockIdx.x % ncb, ob = blockIdx.x / ncb, split = blockIdx.y;
+  // XCD-aware order over (split, block) together: an XCD gets a contiguous run of ids, i.e. all the channel blocks of
+  // its splits, whose gradient / input rows then stay in that XCD's L2 across the blocks
+  const int bid = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+  const int split = bid / (int)gridDim.x, blk = bid - split * (int)gridDim.x;
+  const int cb = blk % ncb, ob = blk / ncb;
   const int n_begin = split * ipS, n_end = min(p.N, n_begin + ipS);
   const int GH = p.GH;
   // operand windows: from this split's first image on
