@@ -2684,6 +2684,11 @@ bool wants_split_weights(const FcdConvDesc* d) {
   if (d->precision != FCD_PREC_BF16X3 || d->Cin % 32 != 0) return false;
   int bm, bn;
   gather_tile(d, bm, bn);
+  // Few output rows (D's deep layers: M = 2048 ... 64 against 2 - 34 M weights) make the launch weight-bound: the
+  // three bf16 planes are 6 bytes per weight in HBM, the fp32 pack 4, so those layers take fp32 weights and split
+  // them in registers (-0.4 ms per step; FCD_BPRE_MINM overrides the row threshold for A/B runs)
+  const char* e = getenv("FCD_BPRE_MINM");
+  if ((long)d->N * d->GH * d->GW < (e ? atol(e) : 2100)) return false;
   return bm == 128 && (bn == 128 || bn == 64);
 }
 
