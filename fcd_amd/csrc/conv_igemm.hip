@@ -76,11 +76,12 @@ struct WgradArgs {
   int P, ND, splitk, ktiles, ktiles_per_split, tiles_m, tiles_n, accumulate;
 };
 
-// slabs [splitk][O][KH*KW*IP] -> parameter layout [O][I][KH][KW].  One block per (o, 64 input
-// channels): slab rows are read along i (coalesced), summed over the splits in a fixed order,
-// transposed through LDS and written as one contiguous run of 64*taps floats.
-constexpr int WR_IC = 64;
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs p) {
+// slabs [splitk][O][KH*KW*IP] -> parameter layout [O][I][KH][KW].  One block per (o, ic input
+// channels; ic = 64, or 256 for the widest layers, whose 32768 blocks of 4 KB were launch-bound): slab rows are
+// read along i (coalesced), summed over the splits in a fixed order, transposed through LDS and written as one
+// contiguous run of ic*taps floats.
+static int wr_ic(int I) { return I >= 1024 ? 256 : 64; }
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs p, const int WR_IC) {
   extern __shared__ float wr_tile[];   // [WR_IC][taps | 1] (odd row stride: no bank conflicts)
   const int taps = p.KH * p.KW, tp = taps | 1;
   const int ichunks = (p.I + WR_IC - 1) / WR_IC;
@@ -3117,8 +3118,9 @@ extern "C" int fcd_conv_wgrad(const FcdWgradDesc* d, const float* gsmall, const 
     rc = launch_wgrad<256, 128, 4, 2>(a, d->precision, st);
   }
   if (rc) return rc;
-  const int blocks = d->O * fcd_cdiv(d->I, WR_IC);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), (size_t)WR_IC * (d->KH * d->KW | 1) * sizeof(float), st, a);
+  const int ic = wr_ic(d->I);
+  const int blocks = d->O * fcd_cdiv(d->I, ic);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), (size_t)ic * (d->KH * d->KW | 1) * sizeof(float), st, a, ic);
   return fcd_check_launch("wgrad_reduce");
 }
 
