@@ -20,6 +20,7 @@ LIB_PATH = os.environ.get("FCD_HIP_LIB") or os.path.join(_HERE, "libfcd_hip.so")
 PREC_F32 = 0
 PREC_BF16 = 1
 PREC_BF16X3 = 2
+PREC_F16X2 = 3     # fp16 x 2 pieces on the 3x3 A-halo layers, BF16X3 elsewhere
 
 c_float_p = C.c_void_p  # device pointers travel as opaque addresses
 
@@ -37,6 +38,7 @@ class ConvDesc(C.Structure):
         ("ooff_h", C.c_int32 * 4), ("ooff_w", C.c_int32 * 4),
         ("splitk", C.c_int32), ("precision", C.c_int32),
         ("act_slope", C.c_float), ("mask_slope", C.c_float),
+        ("a_amax", C.c_void_p), ("w_amax", C.c_void_p),          # FCD_PREC_F16X2 only
     ]
 
 
@@ -67,6 +69,9 @@ PROTOTYPES = {
     "fcd_pack_weight_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "fcd_pack_weight_adj": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "fcd_conv_wants_split_weights": (_I, [C.POINTER(ConvDesc)]),
+    "fcd_conv_weight_format": (_I, [C.POINTER(ConvDesc)]),
+    "fcd_pack_weight_fwd_h2": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "fcd_pack_weight_adj_h2": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "fcd_pack_weight_fwd_x3": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "fcd_pack_weight_adj_x3": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "fcd_head_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),

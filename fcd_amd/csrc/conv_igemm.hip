@@ -37,6 +37,8 @@ struct GatherArgs {
   int tap_inner;   // K-tiles run taps-inside-channel-slices (needs Cin % 32 == 0)
   double* stats;   // optional [N][nphase*stats_cpp][CoutP][2]: per-wave column sums of the output (IN statistics)
   int stats_cpp;   // wave row-chunks per phase per image = GH*GW / WTM
+  const float* a_amax;   // FCD_PREC_F16X2: max |activation operand| and max |weight| (device scalars): the operands are
+  const float* w_amax;   // scaled by powers of two derived from them before the fp16 split
 };
 
 __device__ __forceinline__ float epilogue_value(float v, int co, long o, const GatherArgs& p) {
@@ -153,6 +155,46 @@ __device__ __forceinline__ void split3(const f32x8 f, bf16x8_t& h, bf16x8_t& m, 
   l = __builtin_bit_cast(bf16x8_t, lp);
 }
 
+// FCD_PREC_F16X2: an fp32 value x is written as h + l with h = fp16(s x), l = fp16(s x - h) (round to nearest; the
+// residual is exact in fp32), s a power of two that puts the tensor's largest magnitude at 2^12 .. 2^13 (well inside
+// fp16's range, and 2^26 above the smallest fp16 normal, so both pieces keep their 11 bits for every element within
+// 2^-15 of the largest).  Three fp16 MFMAs (h h, h l, l h) then carry 22+ bits of every operand: measured
+// 8e-8 from float64 on the residual-block convolution (representation only), a quarter of what fp32 accumulation
+// itself adds (tools/fp16x2_probe.py).
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+__host__ __device__ __forceinline__ float pow2_scale_bits(unsigned amax_bits) {
+  const int e = (int)((amax_bits >> 23) & 255u);
+  if (e == 0 || e == 255) return 1.f;                 // zero / denormal / non-finite tensor: no scaling
+  int se = 266 - e;                                   // 2^(12 - (e - 127))
+  se = se < 1 ? 1 : (se > 254 ? 254 : se);
+  union { unsigned u; float f; } c;
+  c.u = (unsigned)se << 23;
+  return c.f;
+}
+__device__ __forceinline__ float pow2_scale(const float* amax) { return pow2_scale_bits(__float_as_uint(*amax)); }
+__device__ __forceinline__ unsigned cvt_pk_f16(float lo, float hi) {
+  unsigned r;
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+__device__ __forceinline__ void unpack_f16(unsigned pk, float& lo, float& hi) {
+  const f16x2_t h = __builtin_bit_cast(f16x2_t, pk);
+  lo = (float)h[0];
+  hi = (float)h[1];
+}
+// four fp32 (already scaled) -> (h, l) as two dwords each
+__device__ __forceinline__ void split2_f16(const u32x4 v, float s, uint2& h, uint2& l) {
+  const float f0 = __uint_as_float(v.x) * s, f1 = __uint_as_float(v.y) * s, f2 = __uint_as_float(v.z) * s, f3 = __uint_as_float(v.w) * s;
+  h.x = cvt_pk_f16(f0, f1);
+  h.y = cvt_pk_f16(f2, f3);
+  float a0, a1, a2, a3;
+  unpack_f16(h.x, a0, a1);
+  unpack_f16(h.y, a2, a3);
+  l.x = cvt_pk_f16(f0 - a0, f1 - a1);
+  l.y = cvt_pk_f16(f2 - a2, f3 - a3);
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   static_assert(N >= 0 && N <= 63, "vmcnt immediate");
@@ -237,7 +279,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 // instead of once per wave), 16-byte chunk slot XOR ((pixel >> 2) & 3) keeps the shifted reads conflict-free.
 constexpr int ah_maxpx(int bm) { return bm == 256 ? 396 : 264; }   // (4 + 2) x 66 or 10 x 34 halo pixels; 128 rows: 4 x 66 or 6 x 34
 
-template <int BM, int BN, int WM, int WN, int S, int PREC, bool N16 = false, bool BPRE = false, bool AH = false>
+template <int BM, int BN, int WM, int WN, int S, int PREC, bool N16 = false, bool BPRE = false, bool AH = false, int NP = 3>
 __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const GatherArgs p, const size_t in_bytes,
                                                                        const unsigned w_bytes) {
   static_assert(!N16 || (BN == 32 && WN == 1 && PREC == FCD_PREC_F32), "N16 shape");
@@ -249,7 +291,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
   static_assert(!BPRE || (PREC == FCD_PREC_BF16X3 && BN % 16 == 0 && !N16), "BPRE shape");
   // BPRE: a B row is 3 planes x 4 chunks (32 bf16 each); one DMA instruction ("unit") covers 16 rows of
   // a plane; units past 3*BN/16 (BN = 64: 12 units on 8 waves) are all-out-of-range dummies
-  constexpr int BUNITS = 3 * BN / 16;
+  static_assert(NP == 3 || (NP == 2 && AH), "two planes (fp16 x 2) only in the A-halo form");
+  constexpr int BUNITS = NP * BN / 16;
   constexpr int AL = AH ? 0 : BM / RPI, BL = BPRE ? (BUNITS + NW - 1) / NW : BN / RPI;   // DMA instructions per wave per K-tile
   constexpr int AOFF = AH ? 0 : BM * 8;                            // float4 chunks of a stage's activation part
   constexpr int STAGE = AOFF + (BPRE ? BL * NW * 64 : BN * 8);     // float4 chunks per stage
@@ -441,6 +484,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
     // all of tile `it`, whose stage takes the DMA of tile it+3, and tile it+1 has landed for the
     // split that runs under the second step's MFMAs.
     struct Pieces { bf16x8_t ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN]; };
+    float a_scale = 1.f;
+    if constexpr (NP == 2) a_scale = pow2_scale(p.a_amax);
     // ---- AH: halo geometry, the staged next slice, the planes
     const int W2 = p.GW + 2, APX = (BM / p.GW + 2) * W2, PB = APX * 64;      // halo row pitch, halo pixels, plane bytes
     const int ah_y0 = (tm * BM - n0 * ghw) / p.GW;                          // first output row of this tile in its image
@@ -475,6 +520,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
         if (hp >= APX) continue;
         unsigned char* dst = Apl + hp * 64 + (((c4 >> 1) ^ ((hp >> 2) & 3)) << 4) + 8 * (c4 & 1);
         const u32x4 v = hst[j];
+        if constexpr (NP == 2) {
+          uint2 h2, l2;
+          split2_f16(v, a_scale, h2, l2);
+          *reinterpret_cast<uint2*>(dst) = h2;
+          *reinterpret_cast<uint2*>(dst + PB) = l2;
+          continue;
+        }
         const float f0 = __uint_as_float(v.x), f1 = __uint_as_float(v.y), f2 = __uint_as_float(v.z), f3 = __uint_as_float(v.w);
         const unsigned h0 = cvt_pk_bf16(f0, f1), h1 = cvt_pk_bf16(f2, f3);
         const float r0 = f0 - __uint_as_float(h0 << 16), r1 = f1 - __uint_as_float(h0 & 0xFFFF0000u);
@@ -498,8 +550,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
           const int hp = hbase[mi] + toff;
           const unsigned char* a = Apl + hp * 64 + (((2 * s2 + lh) ^ ((hp >> 2) & 3)) << 4);
           P.ah[mi] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(a));
-          P.am[mi] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(a + PB));
-          P.al[mi] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(a + 2 * PB));
+          if constexpr (NP == 3) P.am[mi] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(a + PB));
+          P.al[mi] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(a + (NP - 1) * PB));
         } else {
           const int r = wm * WTM + mi * 32 + lr, sw = (r >> 1) & 7;
           const float4 lo = As[r * 8 + (c0 ^ sw)], hi = As[r * 8 + ((c0 + 1) ^ sw)];
@@ -511,8 +563,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
         if constexpr (BPRE) {
           const int r = wn * WTN + ni * 32 + lr, c = (2 * s2 + lh) ^ ((r >> 2) & 3);
           P.bh[ni] = __builtin_bit_cast(bf16x8_t, Bs[(0 * BN + r) * 4 + c]);
-          P.bm[ni] = __builtin_bit_cast(bf16x8_t, Bs[(1 * BN + r) * 4 + c]);
-          P.bl[ni] = __builtin_bit_cast(bf16x8_t, Bs[(2 * BN + r) * 4 + c]);
+          if constexpr (NP == 3) P.bm[ni] = __builtin_bit_cast(bf16x8_t, Bs[(1 * BN + r) * 4 + c]);
+          P.bl[ni] = __builtin_bit_cast(bf16x8_t, Bs[((NP - 1) * BN + r) * 4 + c]);
         } else {
           const int r = wn * WTN + ni * 32 + lr, sw = (r >> 1) & 7;
           const float4 lo = Bs[r * 8 + (c0 ^ sw)], hi = Bs[r * 8 + ((c0 + 1) ^ sw)];
@@ -521,6 +573,27 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
       }
     };
     auto mfma_phase = [&](const Pieces& P, bool with_dma) {
+      if constexpr (NP == 2) {
+        // fp16 x 2: three products, the two small ones into the side accumulator
+#pragma unroll
+        for (int pp = 0; pp < 3; ++pp)
+#pragma unroll
+          for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+              const f16x8_t a = __builtin_bit_cast(f16x8_t, pp == 0 ? P.al[mi] : P.ah[mi]);
+              const f16x8_t b = __builtin_bit_cast(f16x8_t, pp == 1 ? P.bl[ni] : P.bh[ni]);
+              if (pp < 2) acc2[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc2[mi][ni], 0, 0, 0);
+              else acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[mi][ni], 0, 0, 0);
+              if (with_dma) {
+                const int g = (pp * TM + mi) * TN + ni;     // 0 .. 3*TM*TN-1
+#pragma unroll
+                for (int q = 0; q < ND; ++q)
+                  if (q * (3 * TM * TN) / ND == g) issue_one(q);
+              }
+            }
+        return;
+      }
 #pragma unroll
       for (int pp = 0; pp < 6; ++pp)
 #pragma unroll
@@ -782,6 +855,16 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
       for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] += acc2[i][j][r];
+  }
+  if constexpr (NP == 2) {
+    // undo the operand scales (powers of two: exact)
+    const float ia = 1.f / pow2_scale(p.a_amax), iw = 1.f / pow2_scale(p.w_amax);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = acc[i][j][r] * ia * iw;
   }
   __syncthreads();   // rowoff visible even when nk == 0
 
@@ -2540,6 +2623,40 @@ __global__ __launch_bounds__(256) void pack_adj_x3_kernel(const float* __restric
   }
 }
 
+// FCD_PREC_F16X2 operands: two fp16 planes (h, l) of s * w, s = pow2_scale(max |w|); same element orders as the x3 packs
+__device__ __forceinline__ void store_split2(unsigned short* __restrict__ out, long plane_stride, long idx, float v) {
+  const _Float16 h = (_Float16)v;
+  const _Float16 l = (_Float16)(v - (float)h);
+  out[idx] = __builtin_bit_cast(unsigned short, h);
+  out[plane_stride + idx] = __builtin_bit_cast(unsigned short, l);
+}
+__global__ __launch_bounds__(256) void pack_fwd_h2_kernel(const float* __restrict__ w, unsigned short* __restrict__ out,
+                                                          int O, int I, int IP, int taps, const float* __restrict__ amax) {
+  const float sc = pow2_scale(amax);
+  const long total = (long)O * taps * IP;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int i = (int)(idx % IP);
+    const long t2 = idx / IP;
+    const int tap = (int)(t2 % taps), o = (int)(t2 / taps);
+    store_split2(out, total, idx, i < I ? sc * w[((long)o * I + i) * taps + tap] : 0.f);
+  }
+}
+// stride 1 only: out[plane][i][th][tw][o], taps flipped
+__global__ __launch_bounds__(256) void pack_adj_h2_kernel(const float* __restrict__ w, unsigned short* __restrict__ out,
+                                                          int O, int OP, int I, int KH, int KW, const float* __restrict__ amax) {
+  const float sc = pow2_scale(amax);
+  const long total = (long)I * KH * KW * OP;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int o = (int)(idx % OP);
+    long t = idx / OP;
+    const int tw = (int)(t % KW); t /= KW;
+    const int th = (int)(t % KH); t /= KH;
+    const int i = (int)t;
+    const int kh = KH - 1 - th, kw = KW - 1 - tw;
+    store_split2(out, total, idx, o < O ? sc * w[(((long)o * I + i) * KH + kh) * KW + kw] : 0.f);
+  }
+}
+
 // Demangled symbol (as rocprofv3 prints it, without namespace and argument list) of the last convolution /
 // weight-gradient kernel this thread launched: lets a benchmark look the launch up in a rocprofv3 counter
 // file by the kernel that really ran (fcd_last_conv_kernel).
@@ -2658,6 +2775,7 @@ void fill_gather_args(const FcdConvDesc* d, GatherArgs& a) {
   a.tap_inner = (d->Cin % 32 == 0 && d->KH * d->KW > 1) ? 1 : 0;
   a.stats = nullptr;
   a.stats_cpp = 0;
+  a.a_amax = a.w_amax = nullptr;
 
 }
 
@@ -2667,6 +2785,9 @@ extern "C" const char* fcd_last_conv_kernel(void) { return g_last_kernel; }
 
 extern "C" size_t fcd_conv_workspace_bytes(const FcdConvDesc* d) {
   if (!d || d->nphase < 1 || d->Cin <= 0 || d->KH <= 0 || d->KW <= 0) return 0;
+  FcdConvDesc dd = *d;
+  if (dd.precision == FCD_PREC_F16X2) dd.precision = FCD_PREC_BF16X3;
+  d = &dd;
   const int sk = resolve_splitk(d);
   if (sk <= 1) return 0;
   return (size_t)d->nphase * sk * d->N * d->GH * d->GW * d->CoutP * sizeof(float);
@@ -2789,7 +2910,11 @@ int run_gather(const FcdConvDesc* d, GatherArgs& a, hipStream_t st) {
       grid = dim3(a.tiles_m * a.tiles_n, a.nphase * a.splitk);
       note_kernel(bn == 128 ? "conv_gather_dma_kernel<256, 128, 4, 2, 2, 2, false, true>"
                             : "conv_gather_dma_kernel<256, 64, 8, 1, 3, 2, false, true>");
-      if (gather_ahalo(d, 256)) {
+      if (gather_ahalo(d, 256) && a.a_amax) {
+        note_kernel("conv_gather_dma_kernel<256, 128, 4, 2, 3, 2, false, true, true, 2>");
+        hipLaunchKernelGGL((conv_gather_dma_kernel<256, 128, 4, 2, 3, FCD_PREC_BF16X3, false, true, true, 2>), grid, dim3(512), 0, st,
+                           a, in_bytes, (unsigned)((size_t)a.Cout * a.K * 4));
+      } else if (gather_ahalo(d, 256)) {
         note_kernel("conv_gather_dma_kernel<256, 128, 4, 2, 3, 2, false, true, true>");
         hipLaunchKernelGGL((conv_gather_dma_kernel<256, 128, 4, 2, 3, FCD_PREC_BF16X3, false, true, true>), grid, dim3(512), 0, st,
                            a, in_bytes, w_bytes);
@@ -2799,6 +2924,11 @@ int run_gather(const FcdConvDesc* d, GatherArgs& a, hipStream_t st) {
       else
         hipLaunchKernelGGL((conv_gather_dma_kernel<256, 64, 8, 1, 3, FCD_PREC_BF16X3, false, true>), grid, dim3(512), 0, st, a,
                            in_bytes, w_bytes);
+    } else if (bn == 128 && gather_ahalo(d, 128) && a.a_amax) {
+      a.w_phase_stride = (long)d->Cout * a.K;              // two fp16 planes, in units of 4 bytes
+      note_kernel("conv_gather_dma_kernel<128, 128, 4, 2, 3, 2, false, true, true, 2>");
+      hipLaunchKernelGGL((conv_gather_dma_kernel<128, 128, 4, 2, 3, FCD_PREC_BF16X3, false, true, true, 2>), grid, dim3(512), 0, st, a,
+                         in_bytes, (unsigned)((size_t)a.Cout * a.K * 4));
     } else if (bn == 128 && gather_ahalo(d, 128)) {
       note_kernel("conv_gather_dma_kernel<128, 128, 4, 2, 3, 2, false, true, true>");
       hipLaunchKernelGGL((conv_gather_dma_kernel<128, 128, 4, 2, 3, FCD_PREC_BF16X3, false, true, true>), grid, dim3(512), 0, st, a,
@@ -2860,11 +2990,45 @@ int fused_stats_chunks(const FcdConvDesc* d) {
   return (int)(d->nphase * (ghw / wtm));
 }
 
+// FCD_PREC_F16X2 exists only as the two-plane A-halo form; every other shape under it runs as FCD_PREC_BF16X3.  The
+// public entry points work on a normalised copy of the descriptor (precision BF16X3) plus this flag.
+struct NormDesc {
+  FcdConvDesc d;
+  bool h2;
+};
+NormDesc normalise(const FcdConvDesc* d) {
+  NormDesc n;
+  n.d = *d;
+  n.h2 = false;
+  if (d->precision == FCD_PREC_F16X2) {
+    n.d.precision = FCD_PREC_BF16X3;
+    if (validate_conv(&n.d) == FCD_OK && wants_split_weights(&n.d)) {
+      int bm, bn;
+      gather_tile(&n.d, bm, bn);
+      n.h2 = gather_big_tile(&n.d) ? gather_ahalo(&n.d, 256) : (bn == 128 && gather_ahalo(&n.d, 128));
+    }
+  }
+  return n;
+}
+
 }  // namespace
+
+extern "C" int fcd_conv_weight_format(const FcdConvDesc* d) {
+  if (!d) return 0;
+  const NormDesc n = normalise(d);
+  if (n.h2) return 2;
+  return (validate_conv(&n.d) == FCD_OK && wants_split_weights(&n.d)) ? 1 : 0;
+}
 
 extern "C" int fcd_conv_gather(const FcdConvDesc* d, const float* in, const float* w_packed,
                                const float* bias, const float* mask_src, const float* residual,
                                float* out, void* workspace, size_t workspace_bytes, void* stream) {
+  FCD_REQUIRE(d != nullptr, "conv: null descriptor");
+  const NormDesc nd = normalise(d);
+  const float* a_amax = nd.h2 ? d->a_amax : nullptr;
+  const float* w_amax = nd.h2 ? d->w_amax : nullptr;
+  FCD_REQUIRE(!nd.h2 || (a_amax && w_amax), "conv: FCD_PREC_F16X2 needs a_amax and w_amax");
+  d = &nd.d;
   int rc = validate_conv(d);
   if (rc) return rc;
   FCD_REQUIRE(in && w_packed && out, "conv: null tensor");
@@ -2878,11 +3042,14 @@ extern "C" int fcd_conv_gather(const FcdConvDesc* d, const float* in, const floa
   fill_gather_args(d, a);
   a.in = in; a.w = w_packed; a.bias = bias; a.mask = mask_src; a.res = residual; a.out = out;
   a.slab = (float*)workspace;
+  a.a_amax = a_amax; a.w_amax = w_amax;
   return run_gather(d, a, fcd_stream(stream));
 }
 
 extern "C" size_t fcd_conv_gather_stats_workspace_bytes(const FcdConvDesc* d) {
   if (!d || d->nphase < 1 || d->Cin <= 0 || d->KH <= 0 || d->KW <= 0 || d->N <= 0) return 0;
+  const NormDesc nd = normalise(d);
+  d = &nd.d;
   const long hw = (long)d->OH * d->OW;
   const int chunks = fused_stats_chunks(d);
   size_t stats = fcd_instnorm_workspace_bytes(d->N, (int)hw, d->CoutP);
@@ -2894,6 +3061,13 @@ extern "C" size_t fcd_conv_gather_stats_workspace_bytes(const FcdConvDesc* d) {
 extern "C" int fcd_conv_gather_stats(const FcdConvDesc* d, const float* in, const float* w_packed, float* out,
                                      float* mean, float* rstd, float* var_unbiased, float eps, void* workspace,
                                      size_t workspace_bytes, void* stream) {
+  FCD_REQUIRE(d != nullptr, "conv_stats: null descriptor");
+  const FcdConvDesc* d_orig = d;
+  const NormDesc nd = normalise(d);
+  const float* a_amax = nd.h2 ? d->a_amax : nullptr;
+  const float* w_amax = nd.h2 ? d->w_amax : nullptr;
+  FCD_REQUIRE(!nd.h2 || (a_amax && w_amax), "conv_stats: FCD_PREC_F16X2 needs a_amax and w_amax");
+  d = &nd.d;
   int rc = validate_conv(d);
   if (rc) return rc;
   FCD_REQUIRE(in && w_packed && out && mean && rstd, "conv_stats: null tensor");
@@ -2901,7 +3075,7 @@ extern "C" int fcd_conv_gather_stats(const FcdConvDesc* d, const float* in, cons
   FCD_REQUIRE(d->act_slope == 1.f, "conv_stats: the convolution in front of an InstanceNorm has no activation");
   FCD_REQUIRE((long)d->N * d->GH * d->GW * d->nphase == (long)d->N * d->OH * d->OW,
               "conv_stats: the phases must cover the output exactly once");
-  const size_t need = fcd_conv_gather_stats_workspace_bytes(d);
+  const size_t need = fcd_conv_gather_stats_workspace_bytes(d_orig);
   if (workspace == nullptr || workspace_bytes < need) {
     fcd_set_error("conv_stats: workspace %zu < %zu bytes", workspace_bytes, need);
     return FCD_EWORKSPACE;
@@ -2913,6 +3087,7 @@ extern "C" int fcd_conv_gather_stats(const FcdConvDesc* d, const float* in, cons
   fill_gather_args(d, a);
   a.in = in; a.w = w_packed; a.bias = nullptr; a.mask = nullptr; a.res = nullptr; a.out = out;
   a.slab = (float*)workspace;
+  a.a_amax = a_amax; a.w_amax = w_amax;
   const int chunks = fused_stats_chunks(d);
   const long hw = (long)d->OH * d->OW;
   if (chunks == 0) {   // shape does not allow the fused form: convolution, then the two-pass statistics
@@ -3206,8 +3381,26 @@ extern "C" int fcd_pack_weight_fwd(const float* w, float* packed, int O, int I, 
   return fcd_check_launch("pack_fwd");
 }
 
-extern "C" int fcd_conv_wants_split_weights(const FcdConvDesc* d) {
-  return (d && validate_conv(d) == FCD_OK && wants_split_weights(d)) ? 1 : 0;
+extern "C" int fcd_conv_wants_split_weights(const FcdConvDesc* d) { return fcd_conv_weight_format(d) == 1 ? 1 : 0; }
+
+extern "C" int fcd_pack_weight_fwd_h2(const float* w, void* packed, const float* w_amax, int O, int I, int IP, int KH, int KW,
+                                      void* stream) {
+  FCD_REQUIRE(w && packed && w_amax && O > 0 && I > 0 && IP >= I && IP % 4 == 0 && KH > 0 && KW > 0, "pack_weight_fwd_h2: bad arguments");
+  const long total = (long)O * KH * KW * IP;
+  const int blocks = (int)std::min<long>(fcd_cdiv(total, 256), 4096);
+  hipLaunchKernelGGL(pack_fwd_h2_kernel, dim3(blocks), dim3(256), 0, fcd_stream(stream), w, (unsigned short*)packed, O, I, IP,
+                     KH * KW, w_amax);
+  return fcd_check_launch("pack_weight_fwd_h2");
+}
+
+extern "C" int fcd_pack_weight_adj_h2(const float* w, void* packed, const float* w_amax, int O, int OP, int I, int KH, int KW,
+                                      void* stream) {
+  FCD_REQUIRE(w && packed && w_amax && O > 0 && I > 0 && OP >= O && OP % 4 == 0 && KH > 0 && KW > 0, "pack_weight_adj_h2: bad arguments");
+  const long total = (long)I * KH * KW * OP;
+  const int blocks = (int)std::min<long>(fcd_cdiv(total, 256), 4096);
+  hipLaunchKernelGGL(pack_adj_h2_kernel, dim3(blocks), dim3(256), 0, fcd_stream(stream), w, (unsigned short*)packed, O, OP, I,
+                     KH, KW, w_amax);
+  return fcd_check_launch("pack_weight_adj_h2");
 }
 
 extern "C" int fcd_pack_weight_fwd_x3(const float* w, void* packed, int O, int I, int IP, int KH, int KW, void* stream) {

@@ -123,9 +123,27 @@ class ConvGeom:
         return self.k if self.s == 1 else 2
 
 
+def weight_format(d: ConvDesc) -> int:
+    """0 = fp32 pack, 1 = three bf16 planes, 2 = two fp16 planes of the scaled weights (PREC_F16X2 on A-halo layers)."""
+    return int(L.load().fcd_conv_weight_format(C.byref(d)))
+
+
+def set_amax(d: ConvDesc, a_amax: Optional[torch.Tensor], w_amax: Optional[torch.Tensor]) -> ConvDesc:
+    """Attach the device scalars max |activation operand| / max |weight| that PREC_F16X2 scales its operands by."""
+    d.a_amax = a_amax.data_ptr() if a_amax is not None else None
+    d.w_amax = w_amax.data_ptr() if w_amax is not None else None
+    return d
+
+
 def _check_packed(d: ConvDesc, w_packed: torch.Tensor, K: int) -> None:
-    """fp32 pack, or the three-plane bf16 pack where the descriptor asks for it."""
-    if wants_split_weights(d):
+    """fp32 pack, or the three-plane bf16 / two-plane fp16 pack where the descriptor asks for it."""
+    fmt = weight_format(d)
+    if fmt == 2:
+        L.require_gpu_tensor(w_packed, "w_packed (h2)", torch.float16)
+        if not d.a_amax or not d.w_amax:
+            raise RuntimeError("conv: PREC_F16X2 needs ops.set_amax(d, a_amax, w_amax)")
+        want = 2 * d.nphase * d.Cout * K
+    elif fmt == 1:
         L.require_gpu_tensor(w_packed, "w_packed (x3)", torch.bfloat16)
         want = 3 * d.nphase * d.Cout * K
     else:
@@ -254,6 +272,22 @@ def pack_weight_fwd(w: torch.Tensor, g: ConvGeom) -> torch.Tensor:
 def wants_split_weights(d: ConvDesc) -> bool:
     """True where a FCD_PREC_BF16X3 convolution takes three-plane bf16 weights (``*_x3`` packs)."""
     return bool(L.load().fcd_conv_wants_split_weights(C.byref(d)))
+
+
+def pack_weight_fwd_h2(w: torch.Tensor, g: ConvGeom, w_amax: torch.Tensor) -> torch.Tensor:
+    L.require_gpu_tensor(w, "weight")
+    out = torch.empty((2, g.O, g.k, g.k, g.IP), dtype=torch.float16, device=w.device)
+    check(L.load().fcd_pack_weight_fwd_h2(ptr(w), ptr(out), ptr(w_amax), g.O, g.I, g.IP, g.k, g.k, stream()), "pack_weight_fwd_h2")
+    return out
+
+
+def pack_weight_adj_h2(w: torch.Tensor, g: ConvGeom, w_amax: torch.Tensor) -> torch.Tensor:
+    L.require_gpu_tensor(w, "weight")
+    if g.s != 1:
+        raise NotImplementedError("pack_weight_adj_h2: stride 1 only")
+    out = torch.empty((2, g.I, g.k, g.k, g.OP), dtype=torch.float16, device=w.device)
+    check(L.load().fcd_pack_weight_adj_h2(ptr(w), ptr(out), ptr(w_amax), g.O, g.OP, g.I, g.k, g.k, stream()), "pack_weight_adj_h2")
+    return out
 
 
 def pack_weight_fwd_x3(w: torch.Tensor, g: ConvGeom) -> torch.Tensor:

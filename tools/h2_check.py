@@ -1,0 +1,54 @@
+"""FCD_PREC_F16X2 (fp16 x 2 pieces, three MFMAs) A-halo gather kernel against the BF16X3 one and float64: error, time."""
+import os, sys, torch
+import torch.nn.functional as F
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from fcd_amd import ops, _lib as L
+dev = torch.device('cuda:0')
+
+
+def run(O, I, n, h, w, form, prec, scale=1.0, iters=0):
+    g = ops.ConvGeom(O, I, 3, 1, 1)
+    gen = torch.Generator(device=dev).manual_seed(1)
+    cin = I if form == "fwd" else O
+    x = torch.randn(n, h, w, cin, device=dev, generator=gen) * abs(scale)
+    if scale < 0:                 # a few outliers: max |x| / rms(x) = 4096 (what a per-tensor scale is weakest against)
+        x.view(-1)[::1000003] *= 4096.0
+    wt = torch.randn(O, I, 3, 3, device=dev, generator=gen) / (3 * I ** 0.5)
+    d = g.fwd_desc(n, h, w, precision=prec) if form == "fwd" else g.adj_desc(n, h, w, precision=prec)
+    fmt = ops.weight_format(d)
+    keep = []
+    if fmt == 2:
+        wa, xa = wt.abs().max().reshape(1), x.abs().max().reshape(1)
+        keep = [wa, xa]
+        ops.set_amax(d, xa, wa)
+        wp = ops.pack_weight_fwd_h2(wt, g, wa) if form == "fwd" else ops.pack_weight_adj_h2(wt, g, wa)
+    elif fmt == 1:
+        wp = ops.pack_weight_fwd_x3(wt, g) if form == "fwd" else ops.pack_weight_adj_x3(wt, g)
+    else:
+        wp = ops.pack_weight_fwd(wt, g) if form == "fwd" else ops.pack_weight_adj(wt, g)
+    out = ops.conv_gather(d, x, wp)
+    name = L.load().fcd_last_conv_kernel().decode()
+    t = None
+    if iters:
+        for _ in range(50): ops.conv_gather(d, x, wp, out=out)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(); e0.record()
+        for _ in range(iters): ops.conv_gather(d, x, wp, out=out)
+        e1.record(); torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) / iters * 1e3
+    if n * h * w <= 40000:
+        xc, wc = x.double().cpu().permute(0, 3, 1, 2), wt.double().cpu()
+        ref = (F.conv2d(xc, wc, padding=1) if form == "fwd" else F.conv_transpose2d(xc, wc, padding=1)).permute(0, 2, 3, 1)
+    else:
+        ref = None
+    return out.cpu(), ref, name, t
+
+
+for (O, I, n, h, w, form, sc) in [(256, 256, 32, 32, 32, "fwd", 1.0), (256, 256, 32, 32, 32, "adj", 1e-7), (128, 96, 9, 64, 64, "fwd", 1.0),
+                                  (256, 256, 16, 32, 32, "fwd", 300.0), (256, 256, 32, 32, 32, "fwd", -1.0), (256, 256, 32, 32, 32, "adj", -1e-6)]:
+    a, ref, na, ta = run(O, I, n, h, w, form, 2, sc, 100)
+    b, _, nb, tb = run(O, I, n, h, w, form, 3, sc, 100)
+    c, _, nc, tc = run(O, I, n, h, w, form, 0, sc, 0)
+    if ref is None: ref = c.double()
+    e = lambda t: float((t.double() - ref).norm() / ref.norm())
+    print((O, I, n, h, w, form, sc), nb[22:], f"err x3 {e(a):.2e} h2 {e(b):.2e} fp32 {e(c):.2e}  x3 {ta:.1f} us  h2 {tb:.1f} us", flush=True)
