@@ -24,7 +24,7 @@ sys.path.insert(0, ROOT)
 BASE = dict(batch=16, size=128, bands=10, c_dim=1, conv_dim=64, g_repeat=6, d_repeat=6)
 # algorithmic work per image of one G+D step: 12+1 G passes, 15 D passes
 GFLOP_PER_IMG = 293.72
-PEAK_TFLOPS = {"fp32": 157.3, "fp32x3": 157.3, "bf16": 2500.0}   # MI355X_MICROARCH.md dense MFMA peaks
+PEAK_TFLOPS = {"fp32": 157.3, "fp32x3": 157.3, "fp32x2": 157.3, "bf16": 2500.0}   # MI355X_MICROARCH.md dense MFMA peaks (fp16 = bf16)
 
 
 def is_dominant(d):
@@ -38,7 +38,7 @@ def is_dominant(d):
             and d.N == 2 * BASE["batch"] and d.nphase == 1):
         return "dominant"      # the G step runs the generator on paired batches (2 x 16 samples per call)
     m = d.N * d.GH * d.GW
-    if d.precision == 2:       # FCD_PREC_BF16X3
+    if d.precision in (2, 3):  # FCD_PREC_BF16X3 / FCD_PREC_F16X2
         big = -(-m // 256) * -(-d.Cout // 128) * d.nphase >= 256
         return "symbol" if (d.Cout > 64 and d.Cin % 32 == 0 and big) else None
     if d.Cout > 64 and m > 64:
@@ -94,9 +94,15 @@ def dominant_kernel_roofline(precision, dev, in_step_us=None, in_step_launches=0
     n, h, w = 2 * BASE["batch"], 32, 32
     x = torch.randn(n, h, w, 256, device=dev)
     wt = torch.randn(256, 256, 3, 3, device=dev) / 48.0
-    prec = {"fp32": L.PREC_F32, "fp32x3": L.PREC_BF16X3, "bf16": L.PREC_BF16}[precision]
+    prec = {"fp32": L.PREC_F32, "fp32x3": L.PREC_BF16X3, "fp32x2": L.PREC_F16X2, "bf16": L.PREC_BF16}[precision]
     d = g.fwd_desc(n, h, w, precision=prec)
-    wf = ops.pack_weight_fwd_x3(wt, g) if ops.wants_split_weights(d) else ops.pack_weight_fwd(wt, g)
+    fmt = ops.weight_format(d)
+    if fmt == 2:
+        amax_w, amax_x = ops.absmax(wt), ops.absmax(x)
+        ops.set_amax(d, amax_x, amax_w)
+        wf = ops.pack_weight_fwd_h2(wt, g, amax_w)
+    else:
+        wf = ops.pack_weight_fwd_x3(wt, g) if fmt == 1 else ops.pack_weight_fwd(wt, g)
     out = ops.conv_gather(d, x, wf)
     for _ in range(3):
         ops.conv_gather(d, x, wf, out=out)
@@ -123,9 +129,19 @@ def dominant_kernel_roofline(precision, dev, in_step_us=None, in_step_launches=0
     achieved = flops / (ms * 1e-3) / 1e12
     peak = PEAK_TFLOPS[precision]
     launched = L.load().fcd_last_conv_kernel().decode()
-    traffic, traffic_src = (pmc_traffic("resblock_conv_x3_b32", launched) if precision == "fp32x3"
-                            else (None, "traffic profile taken for the fp32x3 kernel only"))
+    traffic, traffic_src = (pmc_traffic("resblock_conv_x3_b32", launched) if precision in ("fp32x3", "fp32x2")
+                            else (None, "traffic profile taken for the default kernel only"))
     extra = {}
+    if precision == "fp32x2":
+        # three fp16 MFMAs per fp32 product group: the scheme's own ceiling is the fp16 peak / 3
+        peak = round(PEAK_TFLOPS["bf16"] / 3, 1)
+        extra = {"executed_fp16_tflops": round(3 * achieved, 1), "fp32_mfma_peak": PEAK_TFLOPS["fp32"],
+                 "frac_of_the_fp32x3_ceiling": round(achieved / (PEAK_TFLOPS["bf16"] / 6), 4),
+                 "note": "algorithmic fp32 FLOPs; peak = dense fp16 MFMA peak / 3 (three fp16 MFMAs per fp32 product group: "
+                         "operands as two fp16 pieces of the power-of-two-scaled values); the fp32x3 scheme of round 1 "
+                         "(six bf16 MFMAs) had 416.7, the exact-fp32 MFMA pipe peaks at 157.3",
+                 "sustained_mfma_rate": "tools/mfma_bf16_probe.hip: 16-bit MFMAs alone sustain 0.76 of the nominal 2.5 PFLOP/s "
+                                        "on this card (power), i.e. 633 TFLOP/s in fp32x2 terms"}
     if precision == "fp32x3":
         # six bf16 MFMAs per fp32 product group: the scheme's own ceiling is the bf16 peak / 6
         peak = round(PEAK_TFLOPS["bf16"] / 6, 1)
@@ -312,7 +328,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--precision", default=os.environ.get("FCD_PRECISION", "fp32x3"), choices=["fp32", "fp32x3", "bf16"],
+    ap.add_argument("--precision", default=os.environ.get("FCD_PRECISION", "fp32x3"), choices=["fp32", "fp32x3", "fp32x2", "bf16"],
                     help="fp32x3 (default): fp32-faithful convolutions on the bf16 matrix pipe (every fp32 operand split "
                          "into three bf16 pieces, fp32 accumulate; same parity bars as fp32, error vs fp64 not larger); "
                          "fp32: exact-fp32 MFMA everywhere; bf16: operands rounded to bf16")
@@ -427,7 +443,10 @@ def main():
                "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": {"fp32": "fp32", "bf16": "bf16 operands, fp32 accumulate",
                          "fp32x3": "fp32 (conv operands as 3 bf16 pieces on the bf16 MFMA pipe, fp32 accumulate; "
-                                   "fp32-faithful: same parity bars as exact fp32)"}[args.precision],
+                                   "fp32-faithful: same parity bars as exact fp32)",
+                         "fp32x2": "fp32 (conv operands as 3 bf16 pieces, or - 3x3 residual-block layers - 2 fp16 pieces of "
+                                   "the power-of-two-scaled values, on the 16-bit MFMA pipe, fp32 accumulate; fp32-faithful: "
+                                   "measured error vs fp64 below the exact-fp32 MFMA chain's, same parity bars)"}[args.precision],
                "data": "synthetic (numpy PCG64 uint16 patches -> [-1,1], nodata rectangle; random-init weights)",
                "config": {"workload": "FCD G+D train step incl. gradient penalty, batch 16/GPU, 128x128x10, "
                                       "6 res blocks, D x6 (BASELINE.json configs[1])",
@@ -443,7 +462,7 @@ def main():
         res["roofline"] = dominant_kernel_roofline(args.precision, dev,
                                                    timer.mean_us("dominant") if timer.pairs else None,
                                                    timer.count("dominant"), symbol=timer.total() if timer.pairs else None)
-        if args.precision == "fp32x3" and world == 1:
+        if args.precision in ("fp32x3", "fp32x2") and world == 1:
             # the same step with exact-fp32 MFMA everywhere (v_mfma_f32_32x32x2_f32), for reference
             solver.set_precision("fp32")
             for _ in range(20):     # also rides out the clock transient ~1-2 s into a run (tools/sustain_probe.py)

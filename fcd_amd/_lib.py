@@ -49,6 +49,7 @@ class WgradDesc(C.Structure):
         ("BH", C.c_int32), ("BW", C.c_int32), ("I", C.c_int32), ("IP", C.c_int32),
         ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
         ("splitk", C.c_int32), ("precision", C.c_int32), ("accumulate", C.c_int32),
+        ("g_amax", C.c_void_p), ("x_amax", C.c_void_p),          # FCD_PREC_F16X2 only
     ]
 
 
@@ -85,6 +86,9 @@ PROTOTYPES = {
     "fcd_instnorm_update_running_batch": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "fcd_instnorm_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P]),
     "fcd_instnorm_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P, _Z, _P]),
+    "fcd_absmax": (_I, [_P, _Z, _P, _P]),
+    "fcd_instnorm_apply_amax": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P]),
+    "fcd_instnorm_bwd_amax": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P, _P, _Z, _P]),
     "fcd_g_prologue": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "fcd_g_epilogue_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "fcd_g_epilogue_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),

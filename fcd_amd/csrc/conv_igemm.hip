@@ -76,6 +76,8 @@ struct WgradArgs {
   float* dw;         // [O][I][KH][KW]
   int N, GH, GW, O, OP, BH, BW, I, IP, KH, KW, stride, pad;
   int P, ND, splitk, ktiles, ktiles_per_split, tiles_m, tiles_n, accumulate;
+  const float* g_amax;   // FCD_PREC_F16X2 (wgrad3_halo kernel): max |gs|, max |xb| (device scalars)
+  const float* x_amax;
 };
 
 // slabs [splitk][O][KH*KW*IP] -> parameter layout [O][I][KH][KW].  One block per (o, ic input
@@ -172,7 +174,21 @@ __host__ __device__ __forceinline__ float pow2_scale_bits(unsigned amax_bits) {
   c.u = (unsigned)se << 23;
   return c.f;
 }
-__device__ __forceinline__ float pow2_scale(const float* amax) { return pow2_scale_bits(__float_as_uint(*amax)); }
+// The maxima arrive as FCD_AMAX_SLOTS partial maxima, one per block of the producing kernel (norm.hip: block_absmax);
+// every lane of the calling wave must be active (4 KB per wave, from L2).
+__device__ __forceinline__ float pow2_scale(const float* amax) {
+  static_assert(FCD_AMAX_SLOTS == 1024, "four float4 per lane");
+  const float4* p = reinterpret_cast<const float4*>(amax) + (threadIdx.x & 63);
+  float m = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float4 v = p[k * 64];
+    m = fmaxf(fmaxf(fmaxf(m, v.x), v.y), fmaxf(v.z, v.w));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  return pow2_scale_bits(__float_as_uint(m));
+}
 __device__ __forceinline__ unsigned cvt_pk_f16(float lo, float hi) {
   unsigned r;
   asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
@@ -2229,6 +2245,7 @@ __device__ __forceinline__ unsigned w3_off(int px, int col) {      // col: chann
   return (unsigned)(px * 128 + (((col >> 4) ^ (((px >> 1) & 1) | (((px >> 3) & 1) << 1))) << 5) + (col & 15) * 2);
 }
 
+template <int NP>   // 3: bf16 x 3 pieces, six MFMAs; 2: FCD_PREC_F16X2, scaled fp16 x 2 pieces, three MFMAs
 __global__ __launch_bounds__(64 * W3_WAVES) void wgrad3_halo_x3_kernel(const WgradArgs p, const int ipS, const int ncb,
                                                                              const size_t gs_bytes, const size_t xb_bytes) {
   __shared__ __attribute__((aligned(16))) unsigned char Xp[4 * W3_XSLOT];
@@ -2263,7 +2280,16 @@ __global__ __launch_bounds__(64 * W3_WAVES) void wgrad3_halo_x3_kernel(const Wgr
     const unsigned voff = ((unsigned)((((img * GH + y) * 32 + px) * p.OP + c) * 4) & okm) | (OOB & ~okm);
     return __builtin_amdgcn_raw_buffer_load_b128(rgs, (int)voff, 0, 0);
   };
-  auto split_store = [&](const u32x4 v, unsigned char* dst, int plane_bytes) {
+  float sg = 1.f, sx = 1.f;
+  if constexpr (NP == 2) { sg = pow2_scale(p.g_amax); sx = pow2_scale(p.x_amax); }
+  auto split_store = [&](const u32x4 v, unsigned char* dst, int plane_bytes, float sc) {
+    if constexpr (NP == 2) {
+      uint2 h2, l2;
+      split2_f16(v, sc, h2, l2);
+      *reinterpret_cast<uint2*>(dst) = h2;
+      *reinterpret_cast<uint2*>(dst + plane_bytes) = l2;
+      return;
+    }
     const float f0 = __uint_as_float(v.x), f1 = __uint_as_float(v.y), f2 = __uint_as_float(v.z), f3 = __uint_as_float(v.w);
     const unsigned h0 = cvt_pk_bf16(f0, f1), h1 = cvt_pk_bf16(f2, f3);
     const float r0 = f0 - __uint_as_float(h0 << 16), r1 = f1 - __uint_as_float(h0 & 0xFFFF0000u);
@@ -2277,9 +2303,9 @@ __global__ __launch_bounds__(64 * W3_WAVES) void wgrad3_halo_x3_kernel(const Wgr
   };
   // input row yy lives in ring slot (yy + 1) & 3
   auto store_x = [&](const u32x4 v, int f, int yy) {
-    if (f < W3_XW * 16) split_store(v, Xp + ((yy + 1) & 3) * W3_XSLOT + w3_off(f >> 4, 4 * (f & 15)), W3_XPLANE);
+    if (f < W3_XW * 16) split_store(v, Xp + ((yy + 1) & 3) * W3_XSLOT + w3_off(f >> 4, 4 * (f & 15)), W3_XPLANE, sx);
   };
-  auto store_g = [&](const u32x4 v, int f, int y) { split_store(v, Gp + (y & 1) * W3_GBUF + w3_off(f >> 4, 4 * (f & 15)), W3_GPLANE); };
+  auto store_g = [&](const u32x4 v, int f, int y) { split_store(v, Gp + (y & 1) * W3_GBUF + w3_off(f >> 4, 4 * (f & 15)), W3_GPLANE, sg); };
 
   // MFMA-wave roles: lane (c = lane & 15, kq = lane >> 4) receives channel c of its tile, pixels 8 kq + 4 j .. + 3 from
   // read j; it supplies the address of pixel 8 kq + 4 j + (c >> 2), channels 4 (c & 3) .. of the tile
@@ -2333,16 +2359,16 @@ __global__ __launch_bounds__(64 * W3_WAVES) void wgrad3_halo_x3_kernel(const Wgr
       for (int ot = 0; ot < 2; ++ot) {
         const int col = 16 * (2 * oh + ot) + 4 * pp;
         gh[ot] = frag(Grow, px, col);
-        gm[ot] = frag(Grow + W3_GPLANE, px, col);
-        gl[ot] = frag(Grow + 2 * W3_GPLANE, px, col);
+        if constexpr (NP == 3) gm[ot] = frag(Grow + W3_GPLANE, px, col);
+        gl[ot] = frag(Grow + (NP - 1) * W3_GPLANE, px, col);
       }
       // one tap ahead: the fragments of tap t+1 are in flight under the MFMAs of tap t
       bf16x8_t xh[2], xm[2], xl[2];
       auto load_tap = [&](int t, int b) {
         const unsigned char* Xrow = Xp + ((y + t / 3) & 3) * W3_XSLOT;      // input row y + th - 1
         xh[b] = frag(Xrow, px + t % 3, xcol);
-        xm[b] = frag(Xrow + W3_XPLANE, px + t % 3, xcol);
-        xl[b] = frag(Xrow + 2 * W3_XPLANE, px + t % 3, xcol);
+        if constexpr (NP == 3) xm[b] = frag(Xrow + W3_XPLANE, px + t % 3, xcol);
+        xl[b] = frag(Xrow + (NP - 1) * W3_XPLANE, px + t % 3, xcol);
       };
       load_tap(0, 0);
 #pragma unroll
@@ -2355,6 +2381,18 @@ __global__ __launch_bounds__(64 * W3_WAVES) void wgrad3_halo_x3_kernel(const Wgr
           __syncthreads();
           store_items(y + 3, y + 2, true);
           load_items(img, y + 4, y + 3);
+        }
+        if constexpr (NP == 2) {
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+            for (int ot = 0; ot < 2; ++ot) {
+              const f16x8_t a = __builtin_bit_cast(f16x8_t, pc == 0 ? gl[ot] : gh[ot]);
+              const f16x8_t b = __builtin_bit_cast(f16x8_t, pc == 1 ? xl[t & 1] : xh[t & 1]);
+              if (pc < 2) acc2[ot][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc2[ot][t], 0, 0, 0);
+              else acc[ot][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[ot][t], 0, 0, 0);
+            }
+          continue;
         }
         // piece pairs outermost (small terms first): consecutive MFMAs go to different accumulators
 #pragma unroll
@@ -2372,6 +2410,7 @@ __global__ __launch_bounds__(64 * W3_WAVES) void wgrad3_halo_x3_kernel(const Wgr
   }
   // D[o = 64 ob + 16 (2 oh + ot) + 4 kq + e][ci = 64 cb + 16 cq + c16] of tap t
   float* __restrict__ dst = p.slab + (long)split * p.O * p.ND;
+  const float isc = NP == 2 ? (1.f / sg) * (1.f / sx) : 1.f;      // powers of two: exact
 #pragma unroll
   for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
@@ -2380,7 +2419,7 @@ __global__ __launch_bounds__(64 * W3_WAVES) void wgrad3_halo_x3_kernel(const Wgr
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int o = ob * 64 + 16 * (2 * oh + ot) + 4 * kq + e;
-        if (o < p.O) dst[(long)o * p.ND + col] = acc[ot][t][e] + acc2[ot][t][e];
+        if (o < p.O) dst[(long)o * p.ND + col] = (acc[ot][t][e] + acc2[ot][t][e]) * isc;
       }
     }
 }
@@ -3148,7 +3187,7 @@ static int halo12w_plan(const FcdWgradDesc* d, int* rows, int* R, int* nch, int*
 // The halo form of the 3x3 weight gradient on 32-pixel-wide images under FCD_PREC_BF16X3 (wgrad3_halo_x3_kernel):
 // number of slabs (= splits over whole images), or 0; *ipS = images per split.
 static int halo3w_plan(const FcdWgradDesc* d, int* ipS) {
-  if (d->splitk > 0 || d->precision != FCD_PREC_BF16X3 || getenv("FCD_NO_WGRAD3")) return 0;
+  if (d->splitk > 0 || (d->precision != FCD_PREC_BF16X3 && d->precision != FCD_PREC_F16X2) || getenv("FCD_NO_WGRAD3")) return 0;
   if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->GW != 32 || d->BW != 32 || d->BH != d->GH) return 0;
   if (d->IP % 64 != 0 || d->OP % 64 != 0 || d->O <= 32 || d->GH < 2) return 0;
   const long blocks = (long)(d->OP / 64) * (d->IP / 64);
@@ -3193,6 +3232,9 @@ static int validate_wgrad(const FcdWgradDesc* d) {
 
 extern "C" size_t fcd_wgrad_workspace_bytes(const FcdWgradDesc* d) {
   if (!d || d->O <= 0 || d->IP <= 0 || d->KH <= 0 || d->KW <= 0) return 0;
+  FcdWgradDesc dd = *d;                  // FCD_PREC_F16X2 exists only in the 3x3 halo kernel; elsewhere it is BF16X3
+  if (dd.precision == FCD_PREC_F16X2) dd.precision = FCD_PREC_BF16X3;
+  d = &dd;
   int rows, R, nch;
   int halo = halo7_plan(d, &rows, &R, &nch);
   int halves;
@@ -3203,6 +3245,13 @@ extern "C" size_t fcd_wgrad_workspace_bytes(const FcdWgradDesc* d) {
 
 extern "C" int fcd_conv_wgrad(const FcdWgradDesc* d, const float* gsmall, const float* xbig, float* dw,
                               void* workspace, size_t workspace_bytes, void* stream) {
+  FCD_REQUIRE(d != nullptr, "wgrad: null descriptor");
+  FcdWgradDesc dd = *d;
+  const bool want_h2 = d->precision == FCD_PREC_F16X2;
+  if (want_h2) dd.precision = FCD_PREC_BF16X3;
+  const float* g_amax = want_h2 ? d->g_amax : nullptr;
+  const float* x_amax = want_h2 ? d->x_amax : nullptr;
+  d = &dd;
   int rc = validate_wgrad(d);
   if (rc) return rc;
   FCD_REQUIRE(gsmall && xbig && dw, "wgrad: null tensor");
@@ -3222,6 +3271,7 @@ extern "C" int fcd_conv_wgrad(const FcdWgradDesc* d, const float* gsmall, const 
   a.ktiles_per_split = fcd_cdiv(a.ktiles, a.splitk);
   a.splitk = fcd_cdiv(a.ktiles, a.ktiles_per_split);
   a.accumulate = d->accumulate;
+  a.g_amax = a.x_amax = nullptr;
   {
     // 32-bit lane offsets inside a workgroup's window: its pixel rows of gs, the images those touch of xb
     const size_t px = (size_t)a.ktiles_per_split * 32;
@@ -3249,9 +3299,17 @@ extern "C" int fcd_conv_wgrad(const FcdWgradDesc* d, const float* gsmall, const 
     a.splitk = slabs3;
     const int ncb = d->IP / 64;
     dim3 grid((d->OP / 64) * ncb, slabs3);
-    note_kernel("wgrad3_halo_x3_kernel");
-    hipLaunchKernelGGL(wgrad3_halo_x3_kernel, grid, dim3(64 * W3_WAVES), 0, st, a, ipS, ncb,
-                       (size_t)a.P * a.OP * 4, (size_t)a.N * a.BH * a.BW * a.IP * 4);
+    if (want_h2) {
+      FCD_REQUIRE(g_amax && x_amax, "wgrad: FCD_PREC_F16X2 needs g_amax and x_amax");
+      a.g_amax = g_amax; a.x_amax = x_amax;
+      note_kernel("wgrad3_halo_x3_kernel<2>");
+      hipLaunchKernelGGL(wgrad3_halo_x3_kernel<2>, grid, dim3(64 * W3_WAVES), 0, st, a, ipS, ncb,
+                         (size_t)a.P * a.OP * 4, (size_t)a.N * a.BH * a.BW * a.IP * 4);
+    } else {
+      note_kernel("wgrad3_halo_x3_kernel");
+      hipLaunchKernelGGL(wgrad3_halo_x3_kernel<3>, grid, dim3(64 * W3_WAVES), 0, st, a, ipS, ncb,
+                         (size_t)a.P * a.OP * 4, (size_t)a.N * a.BH * a.BW * a.IP * 4);
+    }
     rc = fcd_check_launch("conv_wgrad");
   } else if (int hv = 0, slabs12 = halo12w_plan(d, &h_rows, &h_R, &h_nch, &hv); slabs12) {
     a.splitk = slabs12;

@@ -198,11 +198,46 @@ __global__ __launch_bounds__(256) void finalize_kernel(const double* __restrict_
   }
 }
 
+// max |v| of a block's values into the block's slot of amax (FCD_AMAX_SLOTS floats; the value is the maximum of the
+// slots).  No atomics on the usual path: a launch of at most FCD_AMAX_SLOTS blocks gives every block a slot of its own,
+// updated by one thread with a plain read-max-write (launches on a stream are ordered).  Device-scope atomics on this
+// part go to the memory side and serialise per cache line: one per wave cost 300 us per launch, spread over 64 words
+// of two lines still 190 us.  Larger grids fall back to an atomic per block.  Every thread of the block must call it.
+// FCD_PREC_F16X2 scales its operands by the result.
+__device__ __forceinline__ void block_absmax(float m, unsigned* __restrict__ amax, unsigned block, unsigned blocks) {
+  __shared__ float wave_max[4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(wave_max[0], wave_max[1]), fmaxf(wave_max[2], wave_max[3]));
+    const unsigned b = __float_as_uint(m);          // non-negative floats order like their bit patterns
+    unsigned* slot = amax + (block & (FCD_AMAX_SLOTS - 1));
+    if (blocks <= FCD_AMAX_SLOTS) {
+      if (b > *slot) *slot = b;
+    } else if (b > __builtin_nontemporal_load(slot)) {
+      atomicMax(slot, b);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, size_t n4, unsigned* __restrict__ amax) {
+  float m = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    m = fmaxf(fmaxf(fmaxf(m, fabsf(v.x)), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  block_absmax(m, amax, blockIdx.x, gridDim.x);
+}
+
 __global__ __launch_bounds__(256) void in_apply_kernel(const float* __restrict__ z, const float* __restrict__ mean,
                                                        const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const float* __restrict__ res,
-                                                       float* __restrict__ y, long HW, int C, long total4, float act_slope) {
+                                                       float* __restrict__ y, long HW, int C, long total4, float act_slope,
+                                                       unsigned* __restrict__ amax) {
   const int c4 = C / 4;
+  float am = 0.f;
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total4; idx += (long)gridDim.x * 256) {
     const int cc = (int)(idx % c4) * 4;
     const long n = idx / ((long)HW * c4);
@@ -225,7 +260,9 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const float* __restrict__
       o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
     }
     *reinterpret_cast<float4*>(y + idx * 4) = o;
+    am = fmaxf(fmaxf(fmaxf(am, fabsf(o.x)), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w)));
   }
+  if (amax) block_absmax(am, amax, blockIdx.x, gridDim.x);
 }
 
 // One block = one pixel chunk of one image, all channels: a thread keeps the per-(n, c) constants
@@ -237,7 +274,8 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ s12, float* __restrict__ dz, long HW,
                                                            int C, ColPlan pl, float act_slope, int use_running,
                                                            const float* __restrict__ beta, float* __restrict__ dgamma,
-                                                           float* __restrict__ dbeta, int N, int accumulate) {
+                                                           float* __restrict__ dbeta, int N, int accumulate,
+                                                           unsigned* __restrict__ amax) {
   const int n = blockIdx.y, chunk = blockIdx.x;
   const int c4b = pl.c4b;
   const int cbase = blockIdx.z * 1024;
@@ -266,7 +304,9 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const float* __restri
       if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)b : (float)b;
     }
   }
-  if (ty >= pl.rows || cbase / 4 + tx >= pl.c4) return;
+  const bool active = ty < pl.rows && cbase / 4 + tx < pl.c4;
+  float am = 0.f;
+  if (active) {
   const float inv_hw = 1.f / (float)HW;
   const bool need_mask = act_slope != 1.f;
   const bool recompute = need_mask && beta != nullptr;
@@ -308,7 +348,11 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const float* __restri
       }
     }
     *reinterpret_cast<float4*>(dz + off) = make_float4(o[0], o[1], o[2], o[3]);
+    am = fmaxf(fmaxf(fmaxf(am, fabsf(o[0])), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3])));
   }
+  }
+  if (amax)
+    block_absmax(am, amax, (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, gridDim.x * gridDim.y * gridDim.z);
 }
 
 __global__ __launch_bounds__(256) void stats_from_running_kernel(const float* __restrict__ rm, const float* __restrict__ rv,
@@ -527,18 +571,31 @@ extern "C" int fcd_instnorm_update_running(float* running_mean, float* running_v
   return fcd_check_launch("update_running");
 }
 
+extern "C" int fcd_absmax(const float* x, size_t n, float* amax, void* stream) {
+  FCD_REQUIRE(x && amax && n % 4 == 0 && ((uintptr_t)x % 16) == 0, "absmax: null tensor, or a length / address that is not a multiple of 4 floats");
+  const int blocks = (int)std::min<size_t>((n / 4 + 255) / 256, FCD_AMAX_SLOTS);
+  if (n) hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, fcd_stream(stream), x, n / 4, (unsigned*)amax);
+  return fcd_check_launch("absmax");
+}
+
 extern "C" int fcd_instnorm_apply(const float* z, const float* mean, const float* rstd, const float* gamma,
                                   const float* beta, const float* residual, float* y, int N, int HW, int C,
                                   float act_slope, void* stream) {
+  return fcd_instnorm_apply_amax(z, mean, rstd, gamma, beta, residual, y, N, HW, C, act_slope, nullptr, stream);
+}
+
+extern "C" int fcd_instnorm_apply_amax(const float* z, const float* mean, const float* rstd, const float* gamma,
+                                       const float* beta, const float* residual, float* y, int N, int HW, int C,
+                                       float act_slope, float* y_amax, void* stream) {
   int rc = check_nhwc("instnorm_apply", N, HW, C);
   if (rc) return rc;
   FCD_REQUIRE(z && mean && rstd && gamma && beta && y, "instnorm_apply: null tensor");
   FCD_REQUIRE((act_slope >= 0.f && act_slope <= 1.f) || act_slope == FCD_ACT_SILU || act_slope == FCD_ACT_MISH,
               "instnorm_apply: act_slope %g is neither a slope in [0,1] nor an activation code", act_slope);
   const long total4 = (long)N * HW * (C / 4);
-  const int blocks = (int)std::min<long>(fcd_cdiv(total4, 256), 8192);
+  const int blocks = (int)std::min<long>(fcd_cdiv(total4, 256), y_amax ? FCD_AMAX_SLOTS : 8192);   // a slot per block
   hipLaunchKernelGGL(in_apply_kernel, dim3(blocks), dim3(256), 0, fcd_stream(stream), z, mean, rstd, gamma, beta,
-                     residual, y, (long)HW, C, total4, act_slope);
+                     residual, y, (long)HW, C, total4, act_slope, (unsigned*)y_amax);
   return fcd_check_launch("instnorm_apply");
 }
 
@@ -547,6 +604,14 @@ extern "C" int fcd_instnorm_bwd(const float* gy, const float* y, const float* z,
                                 int accumulate, int N,
                                 int HW, int C, float act_slope, int use_running, void* workspace,
                                 size_t workspace_bytes, void* stream) {
+  return fcd_instnorm_bwd_amax(gy, y, z, mean, rstd, gamma, beta, dz, dgamma, dbeta, accumulate, N, HW, C, act_slope,
+                               use_running, nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int fcd_instnorm_bwd_amax(const float* gy, const float* y, const float* z, const float* mean, const float* rstd,
+                                     const float* gamma, const float* beta, float* dz, float* dgamma, float* dbeta,
+                                     int accumulate, int N, int HW, int C, float act_slope, int use_running,
+                                     float* dz_amax, void* workspace, size_t workspace_bytes, void* stream) {
   int rc = check_nhwc("instnorm_bwd", N, HW, C);
   if (rc) return rc;
   FCD_REQUIRE(gy && z && mean && rstd && gamma && dz, "instnorm_bwd: null tensor");
@@ -573,7 +638,7 @@ extern "C" int fcd_instnorm_bwd(const float* gy, const float* y, const float* z,
   rc = fcd_check_launch("instnorm_bwd/finalize");
   if (rc) return rc;
   hipLaunchKernelGGL(in_bwd_apply_kernel, dim3(pl.chunks, N, pl.cblocks), dim3(256), 0, st, gy, y, z, mean, rstd, gamma, s12,
-                     dz, (long)HW, C, pl, act_slope, use_running, beta, dgamma, dbeta, N, accumulate);
+                     dz, (long)HW, C, pl, act_slope, use_running, beta, dgamma, dbeta, N, accumulate, (unsigned*)dz_amax);
   return fcd_check_launch("instnorm_bwd/apply");
 }
 

@@ -61,8 +61,14 @@ class ConvParams(nn.Module):
                 self.bias.uniform_(-bound, bound)
 
     def operand(self, kind: str, geom: ConvGeom, d) -> torch.Tensor:
-        """The packed weights convolution ``d`` wants: fp32, or three bf16 planes (BF16X3, 128x128 tiles)."""
-        return self.packed(kind + "3" if ops.wants_split_weights(d) else kind, geom)
+        """The packed weights convolution ``d`` wants: fp32, three bf16 planes (BF16X3, 128x128 tiles), or two fp16
+        planes of the scaled weights (PREC_F16X2 on the A-halo layers; also sets ``d.w_amax``)."""
+        fmt = ops.weight_format(d)
+        if fmt == 2:
+            t, wa = self.packed(kind + "h", geom)
+            d.w_amax = wa.data_ptr()
+            return t
+        return self.packed(kind + "3" if fmt == 1 else kind, geom)
 
     def packed(self, kind: str, geom: ConvGeom) -> torch.Tensor:
         """Operand layout for the gather kernel, rebuilt when the parameter changed."""
@@ -73,8 +79,16 @@ class ConvParams(nn.Module):
             return hit[1]
         with torch.no_grad():
             wd = w.detach().contiguous()
-            t = {"fwd": ops.pack_weight_fwd, "adj": ops.pack_weight_adj, "fwd3": ops.pack_weight_fwd_x3,
-                 "adj3": ops.pack_weight_adj_x3}[kind](wd, geom)
+            if kind.endswith("h"):
+                hit_a = self._packed.get("amax")
+                if hit_a is None or hit_a[0] != key:
+                    hit_a = (key, ops.absmax(wd))
+                    self._packed["amax"] = hit_a
+                wa = hit_a[1]
+                t = ((ops.pack_weight_fwd_h2 if kind == "fwdh" else ops.pack_weight_adj_h2)(wd, geom, wa), wa)
+            else:
+                t = {"fwd": ops.pack_weight_fwd, "adj": ops.pack_weight_adj, "fwd3": ops.pack_weight_fwd_x3,
+                     "adj3": ops.pack_weight_adj_x3}[kind](wd, geom)
         self._packed[kind] = (key, t)
         return t
 
@@ -242,6 +256,18 @@ class _GeneratorFn(torch.autograd.Function):
         inference = not mod._grad_mode or not any(ctx.needs_input_grad)
         cp = plan[0].geom.IP
         acts = [ops.g_prologue(x, c, cp)]      # acts[i] = input of layer i
+        # PREC_F16X2: max |acts[i]| as device scalars (written by the norm kernel that produces the activation, or by
+        # an absmax launch where a conv that wants it has another producer); amx_ok[i]: already filled
+        h2 = prec == L.PREC_F16X2
+        amx = torch.zeros((len(plan) + 1, ops.AMAX_SLOTS), dtype=torch.float32, device=x.device) if h2 else None
+        amx_ok = [False] * (len(plan) + 1)
+
+        def act_amax(i):
+            if not amx_ok[i]:
+                ops.absmax(acts[i], out=amx[i])
+                amx_ok[i] = True
+            return amx[i]
+
         saved = []                              # per layer: (z, mean, rstd, use_running)
         running = {}                            # (N, C) -> tracked norms whose running statistics this call updates
         pi = 0
@@ -255,7 +281,8 @@ class _GeneratorFn(torch.autograd.Function):
             fuse = nm is not None and not use_running      # statistics ride in the conv's epilogue
             if use_running and inference and ly.kind == "conv" and ly.act_slope <= 1.0:
                 # eval-mode norm folded into the convolution (nothing is kept for a backward pass)
-                d = g.fwd_desc(n, a.shape[1], a.shape[2], precision=prec, act_slope=ly.act_slope)
+                # (the folded operands exist as fp32 / bf16 x 3 packs: PREC_F16X2 runs these layers as BF16X3)
+                d = g.fwd_desc(n, a.shape[1], a.shape[2], precision=L.PREC_BF16X3 if h2 else prec, act_slope=ly.act_slope)
                 wp, shift = ly.conv.folded(g, d, nm, mod._stats_epoch)
                 res = acts[li + 1 + ly.res_from] if ly.res_from is not None else None
                 acts.append(ops.conv_gather(d, a, wp, bias=shift, residual=res))
@@ -268,6 +295,8 @@ class _GeneratorFn(torch.autograd.Function):
             else:
                 d = g.adj_desc(n, a.shape[1], a.shape[2], precision=prec)
                 wp = ly.conv.operand("adj", g, d)
+            if h2 and d.w_amax:
+                d.a_amax = act_amax(li).data_ptr()
             if fuse:
                 z, mean, rstd, varu = ops.conv_gather_stats(d, a, wp, want_var=nm.track)
             else:
@@ -285,7 +314,9 @@ class _GeneratorFn(torch.autograd.Function):
                 # width go out in one launch after the layer loop
                 running.setdefault(mean.shape, []).append((nm.running_mean, nm.running_var, mean, varu))
             res = acts[li + 1 + ly.res_from] if ly.res_from is not None else None
-            y = ops.instnorm_apply(z, mean, rstd, gamma.detach(), beta.detach(), ly.act_slope, residual=res)
+            y = ops.instnorm_apply(z, mean, rstd, gamma.detach(), beta.detach(), ly.act_slope, residual=res,
+                                   amax=amx[li + 1] if h2 else None)
+            amx_ok[li + 1] = h2
             saved.append((z, mean, rstd, use_running))
             acts.append(y)
         for items in running.values():
@@ -299,6 +330,7 @@ class _GeneratorFn(torch.autograd.Function):
         ctx.x = x
         ctx.x_fake = x_fake
         ctx.prec = prec
+        ctx.amx, ctx.amx_ok = amx, amx_ok
         return x_fake
 
     @staticmethod
@@ -326,6 +358,18 @@ class _GeneratorFn(torch.autograd.Function):
             pidx.append(k)
             k += 1 if ly.norm is None else 3
         pending_res = {}       # activation index -> residual gradient to add
+        h2 = prec == L.PREC_F16X2 or prec_w == L.PREC_F16X2
+        amx, amx_ok = ctx.amx, ctx.amx_ok
+        if h2 and amx is None:
+            amx, amx_ok = torch.zeros((len(plan) + 1, ops.AMAX_SLOTS), dtype=torch.float32, device=x.device), [False] * (len(plan) + 1)
+        gmx = torch.zeros((len(plan), ops.AMAX_SLOTS), dtype=torch.float32, device=x.device) if h2 else None   # max |dz| per layer
+
+        def act_amax(i):
+            if not amx_ok[i]:
+                ops.absmax(acts[i], out=amx[i])
+                amx_ok[i] = True
+            return amx[i]
+
         for li in range(len(plan) - 1, -1, -1):
             ly = plan[li]
             z, mean, rstd, use_running = saved[li]
@@ -344,7 +388,8 @@ class _GeneratorFn(torch.autograd.Function):
                                                   ly.norm.weight.detach(), ly.act_slope, use_running,
                                                   want_affine=want_aff, dgamma=sg if direct else None,
                                                   dbeta=sb if direct else None, accumulate=direct,
-                                                  beta=ly.norm.bias.detach())
+                                                  beta=ly.norm.bias.detach(), dz_amax=gmx[li] if h2 else None)
+                dz_ok = h2
                 if not direct:
                     if needs[p0 + 1]:
                         grads[p0 + 1] = dgam
@@ -355,11 +400,22 @@ class _GeneratorFn(torch.autograd.Function):
                     hook.param_ready(ly.norm.weight)
             else:
                 dz = g
+                dz_ok = False
+            h2_layer = h2 and ly.kind == "conv" and gm.k == 3 and gm.s == 1     # the layers PREC_F16X2 kernels exist for
+
+            def dz_amax():
+                nonlocal dz_ok
+                if not dz_ok:
+                    ops.absmax(dz, out=gmx[li])
+                    dz_ok = True
+                return gmx[li]
             # weight gradient
             if needs[p0]:
                 sink = grad_sink(ly.conv.weight, True)     # arena-backed: accumulate into p.grad in place
                 if ly.kind == "conv":
                     wd = gm.wgrad_desc(n, a_in.shape[1], a_in.shape[2], precision=prec_w, accumulate=sink is not None)
+                    if h2_layer and prec_w == L.PREC_F16X2:
+                        ops.set_wgrad_amax(wd, dz_amax(), act_amax(li))
                     dw = ops.conv_wgrad(wd, dz, a_in, dw=sink)
                 else:
                     wd = gm.wgrad_desc(n, dz.shape[1], dz.shape[2], precision=prec_w, accumulate=sink is not None)
@@ -378,7 +434,10 @@ class _GeneratorFn(torch.autograd.Function):
             res = pending_res.pop(li, None)
             if ly.kind == "conv":
                 d = gm.adj_desc(n, dz.shape[1], dz.shape[2], precision=prec)
-                g = ops.conv_gather(d, dz, ly.conv.operand("adj", gm, d), residual=res)
+                wa = ly.conv.operand("adj", gm, d)
+                if h2 and d.w_amax:
+                    d.a_amax = dz_amax().data_ptr()
+                g = ops.conv_gather(d, dz, wa, residual=res)
             else:
                 d = gm.fwd_desc(n, dz.shape[1], dz.shape[2], precision=prec)
                 g = ops.conv_gather(d, dz, ly.conv.operand("fwd", gm, d), residual=res)

@@ -128,10 +128,27 @@ def weight_format(d: ConvDesc) -> int:
     return int(L.load().fcd_conv_weight_format(C.byref(d)))
 
 
+def _amax_ptr(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous() or t.numel() < AMAX_SLOTS or t.data_ptr() % 16:
+        raise ValueError("an amax operand is a contiguous float32 device tensor of AMAX_SLOTS (1024) partial maxima, 16-byte aligned")
+    return t.data_ptr()
+
+
 def set_amax(d: ConvDesc, a_amax: Optional[torch.Tensor], w_amax: Optional[torch.Tensor]) -> ConvDesc:
     """Attach the device scalars max |activation operand| / max |weight| that PREC_F16X2 scales its operands by."""
-    d.a_amax = a_amax.data_ptr() if a_amax is not None else None
-    d.w_amax = w_amax.data_ptr() if w_amax is not None else None
+    d.a_amax = _amax_ptr(a_amax)
+    d.w_amax = _amax_ptr(w_amax)
+    d._amax_refs = (a_amax, w_amax)        # the descriptor holds raw addresses: keep the tensors alive with it
+    return d
+
+
+def set_wgrad_amax(d: WgradDesc, g_amax: Optional[torch.Tensor], x_amax: Optional[torch.Tensor]) -> WgradDesc:
+    """PREC_F16X2 weight gradients: device scalars max |gsmall| / max |xbig| (used where the 3x3 halo kernel applies)."""
+    d.g_amax = _amax_ptr(g_amax)
+    d.x_amax = _amax_ptr(x_amax)
+    d._amax_refs = (g_amax, x_amax)
     return d
 
 
@@ -392,19 +409,38 @@ def instnorm_update_running_batch(items, groups: int = 1) -> None:
                                                          int(groups), IN_MOMENTUM, stream()), "update_running_batch")
 
 
-def instnorm_apply(z, mean, rstd, gamma, beta, act_slope: float, residual=None, out=None):
+AMAX_SLOTS = 1024    # FCD_AMAX_SLOTS: an "amax" is 1024 partial maxima, one per block of the kernel that produced it
+
+
+def absmax(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``max |x|`` as a device "scalar" of AMAX_SLOTS partial maxima (one launch, no host sync); ``out`` (zeroed, or
+    holding earlier maxima) is updated in place."""
+    L.require_gpu_tensor(x, "x")
+    if out is None:
+        out = torch.zeros(AMAX_SLOTS, dtype=torch.float32, device=x.device)
+    xc = x.contiguous()
+    if xc.numel() % 4 or xc.data_ptr() % 16:
+        raise ValueError("absmax: the tensor's length and address must be multiples of 4 floats")
+    _amax_ptr(out)
+    check(L.load().fcd_absmax(ptr(xc), xc.numel(), ptr(out), stream()), "absmax")
+    return out
+
+
+def instnorm_apply(z, mean, rstd, gamma, beta, act_slope: float, residual=None, out=None, amax=None):
+    """``amax`` (a zeroed AMAX_SLOTS-element device tensor): also receives ``max |out|`` (PREC_F16X2 operand scaling)."""
     n, h, w, c = z.shape
     if out is None:
         out = torch.empty_like(z)
-    check(L.load().fcd_instnorm_apply(ptr(z), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(residual), ptr(out), n,
-                                      h * w, c, act_slope, stream()), "instnorm_apply")
+    check(L.load().fcd_instnorm_apply_amax(ptr(z), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(residual), ptr(out), n,
+                                           h * w, c, act_slope, _amax_ptr(amax), stream()), "instnorm_apply")
     return out
 
 
 def instnorm_bwd(gy, y, z, mean, rstd, gamma, act_slope: float, use_running: bool, want_affine: bool = True,
-                 dgamma=None, dbeta=None, accumulate: bool = False, beta=None):
+                 dgamma=None, dbeta=None, accumulate: bool = False, beta=None, dz_amax=None):
     """``dgamma`` / ``dbeta`` given: written (``accumulate``: added to) in place.  ``beta`` given:
-    the activation mask is recomputed from ``z`` and ``y`` may be None."""
+    the activation mask is recomputed from ``z`` and ``y`` may be None.  ``dz_amax`` (zeroed AMAX_SLOTS-element device
+    tensor): also receives ``max |dz|``."""
     n, h, w, c = z.shape
     lib = L.load()
     dz = torch.empty_like(z)
@@ -414,9 +450,9 @@ def instnorm_bwd(gy, y, z, mean, rstd, gamma, act_slope: float, use_running: boo
         dgamma = torch.empty_like(gamma)
         dbeta = torch.empty_like(gamma)
     wp, wn = _ws(lib.fcd_instnorm_workspace_bytes(n, h * w, c), z.device)
-    check(lib.fcd_instnorm_bwd(ptr(gy), ptr(y), ptr(z), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(dz), ptr(dgamma),
-                               ptr(dbeta), int(accumulate), n, h * w, c, act_slope, int(use_running), wp, wn, stream()),
-          "instnorm_bwd")
+    check(lib.fcd_instnorm_bwd_amax(ptr(gy), ptr(y), ptr(z), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(dz), ptr(dgamma),
+                                    ptr(dbeta), int(accumulate), n, h * w, c, act_slope, int(use_running), _amax_ptr(dz_amax),
+                                    wp, wn, stream()), "instnorm_bwd")
     return dz, dgamma, dbeta
 
 

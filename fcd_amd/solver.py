@@ -208,7 +208,8 @@ class FCDSolver(nn.Module):
         accumulate; measured error against fp64 no larger than the exact-fp32 MFMA's, convolutions
         20-40 % faster.  The 10/12-channel image layers keep their exact-fp32 16-wide kernels.
         'bf16': operands rounded to bf16, fp32 accumulate."""
-        p, pw = {"fp32": (L.PREC_F32, None), "fp32x3": (L.PREC_BF16X3, None), "bf16": (L.PREC_BF16, None)}[precision]
+        p, pw = {"fp32": (L.PREC_F32, None), "fp32x3": (L.PREC_BF16X3, None), "bf16": (L.PREC_BF16, None),
+                 "fp32x2": (L.PREC_F16X2, None)}[precision]
         for net in (self.G, self.D):
             net.precision = p
             net.wgrad_precision = pw

@@ -42,6 +42,7 @@ extern "C" {
 #define FCD_PREC_BF16 1  /* operands rounded to bf16 at LDS staging, fp32 accumulate */
 #define FCD_PREC_BF16X3 2 /* each fp32 operand split into three bf16 pieces in registers, six bf16 MFMAs
                              per product group, fp32 accumulate: fp32-faithful at the bf16 matrix rate */
+#define FCD_AMAX_SLOTS 1024 /* an "amax" scalar of FCD_PREC_F16X2 is an array of 1024 floats (one per producing block) whose maximum is the value */
 #define FCD_PREC_F16X2 3  /* 3x3 stride-1 layers that take the A-halo kernel: each fp32 operand scaled by a power of two and
                              split into two fp16 pieces, three fp16 MFMAs (22+ operand bits; fp32 accumulate); every
                              other shape runs as FCD_PREC_BF16X3.  Needs FcdConvDesc.a_amax / w_amax.                */
@@ -121,6 +122,8 @@ typedef struct FcdWgradDesc {
   int32_t splitk;                /* 0 = chosen by the library                    */
   int32_t precision;
   int32_t accumulate;            /* 1: dw += result                              */
+  const float* g_amax;           /* FCD_PREC_F16X2 only (3x3 halo kernel; BF16X3 elsewhere): device scalars      */
+  const float* x_amax;           /* max |gsmall| and max |xbig|; else NULL                                       */
 } FcdWgradDesc;
 
 size_t fcd_wgrad_workspace_bytes(const FcdWgradDesc* d);
@@ -224,6 +227,18 @@ int fcd_instnorm_bwd(const float* gy, const float* y, const float* z, const floa
                      float* dgamma, float* dbeta, int accumulate, int N, int HW, int C,
                      float act_slope, int use_running, void* workspace, size_t workspace_bytes,
                      void* stream);
+/* FCD_PREC_F16X2 support (no reference counterpart: the reference runs cuDNN fp32 / AMP).  The _amax variants are the
+ * calls above that also leave max |y| (max |dz|) in a device "scalar" of FCD_AMAX_SLOTS floats (one slot per
+ * producing block, no atomics; the value is the maximum of the slots): slot = max(slot, ...), so the caller
+ * zeroes the array first; fcd_absmax does the same for any tensor (n floats, a multiple of 4, 16-byte aligned). */
+int fcd_absmax(const float* x, size_t n, float* amax, void* stream);
+int fcd_instnorm_apply_amax(const float* z, const float* mean, const float* rstd, const float* gamma,
+                            const float* beta, const float* residual, float* y, int N, int HW, int C,
+                            float act_slope, float* y_amax, void* stream);
+int fcd_instnorm_bwd_amax(const float* gy, const float* y, const float* z, const float* mean, const float* rstd,
+                          const float* gamma, const float* beta, float* dz, float* dgamma, float* dbeta,
+                          int accumulate, int N, int HW, int C, float act_slope, int use_running,
+                          float* dz_amax, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Generator prologue / epilogue (fixed_point_gan.py:73-75 and :78-82).

@@ -482,3 +482,125 @@ def test_wgrad3_halo_x3(dev, shape, monkeypatch):
         acc = torch.full_like(dw, 0.25)
         ops.conv_wgrad(g.wgrad_desc(n, h, 32, precision=2, accumulate=True), gd, xd, dw=acc)
         assert relerr(acc.cpu() - 0.25, ref) <= 1e-5
+
+
+# FCD_PREC_F16X2: (O, I, N, H, W, form, scale of the activation operand)
+H2_GEOMS = [
+    (256, 256, 32, 32, 32, "fwd", 1.0),
+    (256, 256, 16, 32, 32, "adj", 3e-6),       # gradients of the size the gradient-penalty backward carries
+    (128, 96, 9, 64, 64, "fwd", 4000.0),
+    (64, 192, 25, 16, 32, "adj", 1.0),
+]
+
+
+@pytest.mark.parametrize("geom", H2_GEOMS)
+def test_gather_a_halo_f16x2(dev, geom):
+    """FCD_PREC_F16X2 on the A-halo 3x3 convolutions: operands scaled by a power of two taken from their max |.|
+    (ops.absmax: FCD_AMAX_SLOTS per-block maxima) and split into two fp16 pieces, three fp16 MFMAs per product group.
+    Against torch in float64 the error stays at the BF16X3 level (<= 1e-6 of max |result|, the bar of the exact-fp32
+    kernels is 1e-5) whatever the magnitude of the operands, also with a few outliers 1000 x the rest (values far
+    below the maximum lose relative precision in the split, not absolute)."""
+    from fcd_amd import _lib as L, ops
+    O, I, N, H, W, form, sc = geom
+    g = ops.ConvGeom(O, I, 3, 1, 1)
+    gen = torch.Generator().manual_seed(21)
+    wt = torch.randn(O, I, 3, 3, generator=gen) / (3 * I ** 0.5)
+    wd = wt.to(dev)
+    wa = ops.absmax(wd)
+    assert wa.numel() == ops.AMAX_SLOTS and float(wa.max()) == float(wt.abs().max())
+    for outliers in (False, True):
+        if form == "fwd":
+            x = torch.randn(N, I, H, W, generator=gen) * sc
+            if outliers:
+                x.view(-1)[::40961] *= 1000.0
+            b = torch.randn(O, generator=gen) * sc
+            d = g.fwd_desc(N, H, W, precision=L.PREC_F16X2, act_slope=0.01)
+            assert ops.weight_format(d) == 2
+            xd = to_nhwc(x, g.IP).to(dev)
+            ops.set_amax(d, ops.absmax(xd), wa)
+            wp = ops.pack_weight_fwd_h2(wd, g, wa)
+            got = ops.conv_gather(d, xd, wp, bias=b.to(dev))
+            ref = F.leaky_relu(F.conv2d(x.double(), wt.double(), b.double(), 1, 1), 0.01)
+            cref = O
+        else:
+            gy = torch.randn(N, O, H, W, generator=gen) * sc
+            if outliers:
+                gy.view(-1)[::40961] *= 1000.0
+            mask = torch.randn(N, I, H, W, generator=gen)
+            d = g.adj_desc(N, H, W, precision=L.PREC_F16X2, mask_slope=0.01)
+            assert ops.weight_format(d) == 2
+            gd, md = to_nhwc(gy, g.OP).to(dev), to_nhwc(mask, g.IP).to(dev)
+            ops.set_amax(d, ops.absmax(gd), wa)
+            wp = ops.pack_weight_adj_h2(wd, g, wa)
+            got = ops.conv_gather(d, gd, wp, mask=md)
+            ref = F.conv_transpose2d(gy.double(), wt.double(), None, 1, 1) * torch.where(mask > 0, 1.0, 0.01)
+            cref = I
+        assert L.load().fcd_last_conv_kernel().endswith(b"true, true, 2>")
+        assert relerr(from_nhwc(got.cpu(), cref).double(), ref) <= 1e-6
+
+
+def test_f16x2_without_amax_is_refused(dev):
+    """A PREC_F16X2 A-halo convolution needs both maxima: the library refuses the launch instead of guessing a scale."""
+    from fcd_amd import _lib as L, ops
+    g = ops.ConvGeom(256, 256, 3, 1, 1)
+    d = g.fwd_desc(32, 32, 32, precision=L.PREC_F16X2)
+    x = torch.zeros(32, 32, 32, 256, device=dev)
+    wd = torch.zeros(256, 256, 3, 3, device=dev)
+    wp = ops.pack_weight_fwd_h2(wd, g, ops.absmax(wd))
+    with pytest.raises(RuntimeError):
+        ops.conv_gather(d, x, wp)
+    with pytest.raises(ValueError):
+        ops.set_amax(d, torch.zeros(1, device=dev), torch.zeros(1, device=dev))
+
+
+@pytest.mark.parametrize("shape", [(256, 256, 16, 4, 1.0, 1.0), (128, 192, 40, 5, 2e-5, 30.0), (254, 128, 30, 3, 500.0, 1e-3)])
+def test_wgrad3_halo_f16x2(dev, shape):
+    """FCD_PREC_F16X2 weight gradient of the residual blocks' 3x3 convolutions (wgrad3_halo_x3_kernel<2>): both operands
+    as two fp16 planes of the scaled values; <= 1e-6 of max |dW| from torch in float64 across operand magnitudes, and
+    accumulation into an existing gradient."""
+    from fcd_amd import _lib as L, ops
+    O, I, n, h, sg, sx = shape
+    g = ops.ConvGeom(O, I, 3, 1, 1)
+    gen = torch.Generator().manual_seed(23)
+    x = torch.randn(n, I, h, 32, generator=gen) * sx
+    gy = torch.randn(n, O, h, 32, generator=gen) * sg
+    xd, gd = to_nhwc(x, g.IP).to(dev), to_nhwc(gy, g.OP).to(dev)
+    d = ops.set_wgrad_amax(g.wgrad_desc(n, h, 32, precision=L.PREC_F16X2), ops.absmax(gd), ops.absmax(xd))
+    dw = ops.conv_wgrad(d, gd, xd)
+    assert L.load().fcd_last_conv_kernel() == b"wgrad3_halo_x3_kernel<2>"
+    ref = torch.nn.grad.conv2d_weight(x.double(), (O, I, 3, 3), gy.double(), stride=1, padding=1)
+    assert relerr(dw.cpu(), ref) <= 1e-6
+    base = float(ref.abs().max()) * 0.25
+    acc = torch.full_like(dw, base)
+    d2 = ops.set_wgrad_amax(g.wgrad_desc(n, h, 32, precision=L.PREC_F16X2, accumulate=True), ops.absmax(gd), ops.absmax(xd))
+    ops.conv_wgrad(d2, gd, xd, dw=acc)
+    assert relerr(acc.cpu() - base, ref) <= 1e-5
+    # without the maxima the launch is refused (no guessed scale)
+    with pytest.raises(RuntimeError):
+        ops.conv_wgrad(g.wgrad_desc(n, h, 32, precision=L.PREC_F16X2), gd, xd)
+
+
+def test_absmax_and_norm_amax(dev):
+    """max |.| producers of PREC_F16X2: fcd_absmax, and the InstanceNorm apply / backward kernels' fused maxima, equal
+    torch's abs().max() of the tensor they wrote (as the maximum over the FCD_AMAX_SLOTS per-block slots), including
+    accumulation into an existing array and grids larger than the slot count."""
+    from fcd_amd import ops
+    gen = torch.Generator().manual_seed(5)
+    for shape in [(2, 8, 8, 64), (32, 32, 32, 256), (3, 128, 128, 64), (16, 128, 128, 64)]:
+        z = torch.randn(*shape, generator=gen).to(dev) * 3
+        a = ops.absmax(z)
+        assert float(a.max()) == float(z.abs().max())
+        ops.absmax(z * 0.5, out=a)
+        assert float(a.max()) == float(z.abs().max())
+        N, H, W, C = shape
+        mean, rstd, _ = ops.instnorm_stats(z)
+        gamma, beta = torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev)
+        am = torch.zeros(ops.AMAX_SLOTS, device=dev)
+        y = ops.instnorm_apply(z, mean, rstd, gamma, beta, act_slope=0.0, amax=am)
+        assert float(am.max()) == float(y.abs().max())
+        gy = torch.randn(*shape, generator=gen).to(dev) * 1e-4
+        gm = torch.zeros(ops.AMAX_SLOTS, device=dev)
+        dz, _, _ = ops.instnorm_bwd(gy, y, z, mean, rstd, gamma, 0.0, False, dz_amax=gm)
+        assert float(gm.max()) == float(dz.abs().max())
+        dz0, _, _ = ops.instnorm_bwd(gy, y, z, mean, rstd, gamma, 0.0, False)
+        assert torch.equal(dz, dz0)

@@ -54,7 +54,7 @@ BIG = np.load(os.path.join(GOLD, "full_grad_samples.npz"))
 #     extreme-value statistic of a step with ReLU / LeakyReLU / L1 kinks: a single activation-mask flip moves a
 #     few elements by O(1) of their value in either fp32 evaluation (worst ratio 9.8, D features.1.0.weight).
 # The measured errors of every tensor are written to gpurun_out/full_parity_*.json.
-FACTORS = {"fp32x3": (1.5, 3.0), "fp32": (2.0, 12.0)}
+FACTORS = {"fp32x3": (1.5, 3.0), "fp32x2": (1.5, 3.0), "fp32": (2.0, 12.0)}
 OUT_DIR = os.path.join(os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(__file__))), "gpurun_out")
 
 
@@ -102,7 +102,7 @@ def check_grads(net, tag, sc, prec):
 
 
 # fp32x3: weight gradients on the bf16 pipe with 3-way split operands (same bars as exact fp32)
-@pytest.mark.parametrize("prec", ["fp32", "fp32x3"])
+@pytest.mark.parametrize("prec", ["fp32", "fp32x3", "fp32x2"])
 def test_full_d_step(full, prec):
     sc, make, b, alpha = full
     s = make(prec)
@@ -115,7 +115,7 @@ def test_full_d_step(full, prec):
     print("full D-step", prec, ": worst error / bar =", check_grads(s.D, "d", sc, prec))
 
 
-@pytest.mark.parametrize("prec", ["fp32", "fp32x3"])
+@pytest.mark.parametrize("prec", ["fp32", "fp32x3", "fp32x2"])
 def test_full_g_step(full, prec):
     sc, make, b, alpha = full
     s = make(prec)

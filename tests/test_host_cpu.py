@@ -26,8 +26,12 @@ def test_library_exports_every_declared_symbol():
 
 def test_descriptor_structs_match_header_layout():
     from fcd_amd import _lib
-    assert ctypes.sizeof(_lib.ConvDesc) == 4 * (15 + 16 + 2) + 8
-    assert ctypes.sizeof(_lib.WgradDesc) == 4 * 16
+    # sizeof(FcdConvDesc) / sizeof(FcdWgradDesc) of include/fcd_hip.h (gcc, x86-64): 33 ints + padding + 3 pointers;
+    # 16 ints + 2 pointers
+    assert ctypes.sizeof(_lib.ConvDesc) == 160
+    assert ctypes.sizeof(_lib.WgradDesc) == 80
+    assert _lib.ConvDesc.a_amax.offset == 144 and _lib.ConvDesc.w_amax.offset == 152
+    assert _lib.WgradDesc.g_amax.offset == 64 and _lib.WgradDesc.x_amax.offset == 72
 
 
 def test_workspace_queries_run_without_gpu():

@@ -77,7 +77,7 @@ def test_discriminator_forward(dev, tiny):
     assert relerr(feat[0], torch.from_numpy(z["D_feat"])) <= TOL
 
 
-@pytest.mark.parametrize("prec", ["fp32", "fp32x3"])
+@pytest.mark.parametrize("prec", ["fp32", "fp32x3", "fp32x2"])
 def test_d_step_losses_and_grads(dev, tiny, prec):
     z, sc = tiny
     s = build(z, sc["cfg"], dev)
@@ -105,7 +105,7 @@ def test_d_step_losses_and_grads(dev, tiny, prec):
     print("D-step worst grad rel-err", worst)
 
 
-@pytest.mark.parametrize("prec", ["fp32", "fp32x3"])
+@pytest.mark.parametrize("prec", ["fp32", "fp32x3", "fp32x2"])
 def test_g_step_losses_and_grads(dev, tiny, prec):
     z, sc = tiny
     s = build(z, sc["cfg"], dev)
@@ -419,7 +419,7 @@ SHAPES = {
 
 
 @pytest.mark.parametrize("name", list(SHAPES))
-@pytest.mark.parametrize("prec", ["fp32", "fp32x3"])
+@pytest.mark.parametrize("prec", ["fp32", "fp32x3", "fp32x2"])
 def test_other_shapes_vs_oracle(dev, name, prec):
     from fcd_amd import FCDSolver
     from oracle import fcd_oracle as O
@@ -565,7 +565,7 @@ def test_all_nodata_sample_and_constant_channels(dev):
 # --------------------------------------------------------------------------- #
 # eval-mode folding, arena safety (round-1 advisor findings)
 # --------------------------------------------------------------------------- #
-@pytest.mark.parametrize("prec", ["fp32", "fp32x3"])
+@pytest.mark.parametrize("prec", ["fp32", "fp32x3", "fp32x2"])
 def test_folded_eval_equals_unfolded_eval(dev, tiny, prec):
     """Under torch.no_grad() the eval-mode generator folds the tracked InstanceNorms into the
     convolutions (ConvParams.folded); with grad enabled and parameters requiring grad it takes the

@@ -18,7 +18,7 @@ def run(O, I, n, h, w, form, prec, scale=1.0, iters=0):
     fmt = ops.weight_format(d)
     keep = []
     if fmt == 2:
-        wa, xa = wt.abs().max().reshape(1), x.abs().max().reshape(1)
+        wa, xa = ops.absmax(wt), ops.absmax(x)
         keep = [wa, xa]
         ops.set_amax(d, xa, wa)
         wp = ops.pack_weight_fwd_h2(wt, g, wa) if form == "fwd" else ops.pack_weight_adj_h2(wt, g, wa)
