@@ -140,8 +140,9 @@ def dominant_kernel_roofline(precision, dev, in_step_us=None, in_step_launches=0
                  "note": "algorithmic fp32 FLOPs; peak = dense fp16 MFMA peak / 3 (three fp16 MFMAs per fp32 product group: "
                          "operands as two fp16 pieces of the power-of-two-scaled values); the fp32x3 scheme of round 1 "
                          "(six bf16 MFMAs) had 416.7, the exact-fp32 MFMA pipe peaks at 157.3",
-                 "sustained_mfma_rate": "tools/mfma_bf16_probe.hip: 16-bit MFMAs alone sustain 0.76 of the nominal 2.5 PFLOP/s "
-                                        "on this card (power), i.e. 633 TFLOP/s in fp32x2 terms"}
+                 "sustained_mfma_rate": "tools/mfma_f16_probe.hip (random operands, two waves per SIMD, long launches): fp16 MFMAs "
+                                        "alone sustain 0.62 of the nominal 2.5 PFLOP/s on this card (power), 0.53 with this "
+                                        "kernel's 8 ds_read_b128 per 12 MFMAs beside them: 517 / 440 TFLOP/s in fp32x2 terms"}
     if precision == "fp32x3":
         # six bf16 MFMAs per fp32 product group: the scheme's own ceiling is the bf16 peak / 6
         peak = round(PEAK_TFLOPS["bf16"] / 6, 1)
@@ -171,9 +172,9 @@ def dominant_kernel_roofline(precision, dev, in_step_us=None, in_step_launches=0
             "clock_note": "sysfs pp_dpm_sclk while this kernel runs back to back; the peaks above assume 2400 MHz, "
                           "so frac at the clock the card actually holds is frac * 2400 / engine_clock_mhz_under_kernel",
             "traffic": traffic, "traffic_source": traffic_src,
-            "algorithmic_bytes": int(2 * n * h * w * 256 * 4 + 256 * 256 * 9 * 6),
+            "algorithmic_bytes": int(2 * n * h * w * 256 * 4 + 256 * 256 * 9 * (4 if precision == "fp32x2" else 6)),
             "traffic_unit": "HBM-side bytes per launch (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, looked up by the launched "
-                            "kernel's symbol); algorithmic: input + output fp32 once + the three bf16 weight planes"}
+                            "kernel's symbol); algorithmic: input + output fp32 once + the weight planes (three bf16, or two fp16 under fp32x2)"}
 
 
 def hbm_kernel_roofline(dev, iters=20):
@@ -328,10 +329,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--precision", default=os.environ.get("FCD_PRECISION", "fp32x3"), choices=["fp32", "fp32x3", "fp32x2", "bf16"],
-                    help="fp32x3 (default): fp32-faithful convolutions on the bf16 matrix pipe (every fp32 operand split "
-                         "into three bf16 pieces, fp32 accumulate; same parity bars as fp32, error vs fp64 not larger); "
-                         "fp32: exact-fp32 MFMA everywhere; bf16: operands rounded to bf16")
+    ap.add_argument("--precision", default=os.environ.get("FCD_PRECISION", "fp32x2"), choices=["fp32", "fp32x3", "fp32x2", "bf16"],
+                    help="fp32x2 (default): fp32-faithful convolutions on the 16-bit matrix pipe: the 3x3 residual-block "
+                         "layers take their operands as two fp16 pieces of the power-of-two-scaled fp32 values (three MFMAs "
+                         "per product group), every other layer as in fp32x3; fp32x3: every fp32 operand split into three "
+                         "bf16 pieces (six MFMAs); both: fp32 accumulate, same parity bars as fp32, error vs fp64 not "
+                         "larger; fp32: exact-fp32 MFMA everywhere; bf16: operands rounded to bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default=os.environ.get("FCD_DIST_BACKEND", "nccl"),
                     help="torch.distributed backend: nccl (= RCCL over xGMI); gloo only to rehearse the "
@@ -476,6 +479,20 @@ def main():
             solver.set_precision(args.precision)
             res["exact_fp32_mfma"] = {"value": round(BASE["batch"] * args.steps / dt1, 2), "unit": "images/sec",
                                       "ms_per_step": round(dt1 / args.steps * 1e3, 3)}
+            if args.precision == "fp32x2":
+                # round 1's split scheme everywhere (three bf16 pieces, six MFMAs per product group), for reference
+                solver.set_precision("fp32x3")
+                for _ in range(10):
+                    step()
+                torch.cuda.synchronize()
+                t3 = time.perf_counter()
+                for _ in range(args.steps):
+                    step()
+                torch.cuda.synchronize()
+                dt3 = time.perf_counter() - t3
+                solver.set_precision(args.precision)
+                res["fp32x3_variant"] = {"value": round(BASE["batch"] * args.steps / dt3, 2), "unit": "images/sec",
+                                         "ms_per_step": round(dt3 / args.steps * 1e3, 3)}
             # the bf16-MFMA variant of BASELINE.json configs[1] (operands rounded to bf16, fp32 accumulate): an
             # extra field, never `value`.  Its losses meet north_star's 1e-2; parameter gradients of this step do
             # not in ANY bf16 implementation (torch's own CPU autocast: profiles/r2_bf16_autocast_cpu_*.json)

@@ -628,6 +628,73 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
             }
           }
     };
+    // fp16 x 2, A-halo form: the MFMAs of one k16-step with the fragment reads of the next one between its three
+    // product groups, each operand read as soon as its register set is free (al after al.bh, bh after ah.bh, ah and bl
+    // after ah.bl) and at least one group (4 MFMAs) ahead of its first use; fenced, because left alone the scheduler
+    // sinks every read to just before its MFMA, and reading the whole next step in front of this one needs 64 fragment
+    // registers and spills.  Same products in the same order per accumulator as mfma_phase.  Measured: the same time
+    // as the scheduler's own order (the SIMD's second wave covers the latency either way): the kernel runs at 85 % of
+    // what a bare loop of fp16 MFMAs with this ratio of ds_read_b128 sustains under the card's power limit
+    // (tools/mfma_f16_probe.hip: 0.53 of the nominal peak; 0.62 with no reads at all).
+    auto phase2 = [&](const Pieces& C, Pieces& N, int stgN, int s2N, int toffN, bool with_dma) {
+      if constexpr (AH && NP == 2) {
+        const unsigned char* an[TM];
+        const float4* bn_[TN];
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+          const int hp = hbase[mi] + toffN;
+          an[mi] = Apl + hp * 64 + (((2 * s2N + lh) ^ ((hp >> 2) & 3)) << 4);
+        }
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+          const int r = wn * WTN + ni * 32 + lr;
+          bn_[ni] = smem + stgN * STAGE + AOFF + r * 4 + ((2 * s2N + lh) ^ ((r >> 2) & 3));
+        }
+        auto dma = [&](int grp) {
+          if (with_dma) {
+#pragma unroll
+            for (int q = 0; q < ND; ++q)
+              if (q * 3 / ND == grp) issue_one(q);
+          }
+        };
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < TN; ++ni)
+            acc2[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, C.al[mi]),
+                                                                  __builtin_bit_cast(f16x8_t, C.bh[ni]), acc2[mi][ni], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) N.al[mi] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(an[mi] + PB));
+        dma(0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < TN; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, C.ah[mi]),
+                                                                 __builtin_bit_cast(f16x8_t, C.bh[ni]), acc[mi][ni], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) N.bh[ni] = __builtin_bit_cast(bf16x8_t, bn_[ni][0]);
+        dma(1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < TN; ++ni)
+            acc2[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, C.ah[mi]),
+                                                                  __builtin_bit_cast(f16x8_t, C.bl[ni]), acc2[mi][ni], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) N.ah[mi] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(an[mi]));
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) N.bl[ni] = __builtin_bit_cast(bf16x8_t, bn_[ni][BN * 4]);
+        dma(2);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
     if constexpr (AH) {
       ah_load(0);
       ah_store();
@@ -651,8 +718,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
       // carries the slice change between its two k16-steps
       auto body = [&](auto bnd, int it, int toff, int toff_next, int cs) {
         const int next = stage == S - 1 ? 0 : stage + 1;
-        load_split(stage, 1, P1, toff);
-        mfma_phase(P0, false);
+        if constexpr (NP == 2) {
+          phase2(P0, P1, stage, 1, toff, false);
+        } else {
+          load_split(stage, 1, P1, toff);
+          mfma_phase(P0, false);
+        }
         wait_vmcnt<(S - 2) * ND>();
         __builtin_amdgcn_s_barrier();     // every wave is done reading tile it -- and, at the last tap, the planes
         issue_prepare(stage, it + S < nk);
@@ -663,6 +734,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
           __builtin_amdgcn_s_barrier();
           ah_load(cs + 2);                // zeros past the last slice
           load_split(next, 0, P0, toff_next);
+        } else if constexpr (NP == 2) {
+          phase2(P1, P0, next, 0, toff_next, true);
         } else {
           load_split(next, 0, P0, toff_next);
           mfma_phase(P1, true);

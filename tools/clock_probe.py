@@ -1,6 +1,6 @@
 """Engine clock while the residual-block convolution (32 samples) runs back to back for a few seconds: a
 child process loops the kernel, this process polls rocm-smi (read-only).
-    python tools/clock_probe.py <precision 0|1|2> [wgrad]"""
+    python tools/clock_probe.py <precision 0|1|2|3> [wgrad]"""
 import os, subprocess, sys, time
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 prec = sys.argv[1] if len(sys.argv) > 1 else "2"
@@ -14,10 +14,17 @@ g = ops.ConvGeom(256, 256, 3, 1, 1)
 x = torch.randn(32, 32, 32, 256, device=dev); wt = torch.randn(256, 256, 3, 3, device=dev) / 48
 prec = %s
 d = g.fwd_desc(32, 32, 32, precision=prec)
-wf = ops.pack_weight_fwd_x3(wt, g) if prec == 2 else ops.pack_weight_fwd(wt, g)
+fmt = ops.weight_format(d)
+if fmt == 2:
+    wa = ops.absmax(wt)
+    ops.set_amax(d, ops.absmax(x), wa)
+    wf = ops.pack_weight_fwd_h2(wt, g, wa)
+else:
+    wf = ops.pack_weight_fwd_x3(wt, g) if fmt == 1 else ops.pack_weight_fwd(wt, g)
 if %s:
     gy = torch.randn(32, 32, 32, 256, device=dev)
     wd = g.wgrad_desc(32, 32, 32, precision=prec)
+    if prec == 3: ops.set_wgrad_amax(wd, ops.absmax(gy), ops.absmax(x))
     dw = ops.conv_wgrad(wd, gy, x)
     run = lambda: ops.conv_wgrad(wd, gy, x, dw)
 else:

@@ -58,7 +58,14 @@ def main():
             out.setdefault(label, {})[sym] = {"fetch_size_kb": sum(f) / len(f), "write_size_kb": sum(w) / len(w), "launches": len(f),
                                               "files": [f"profiles/{tag}_{label}_pmc_FETCH_SIZE.csv",
                                                         f"profiles/{tag}_{label}_pmc_WRITE_SIZE.csv"]}
-    json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_traffic.json"), "w"), indent=1)
+    # TRAFFIC_JSON=<file>: merge into an existing file (another precision's symbols under the same labels)
+    path = os.environ.get("TRAFFIC_JSON") or os.path.join(ROOT, "profiles", f"{tag}_traffic.json")
+    if os.environ.get("TRAFFIC_JSON") and os.path.exists(path):
+        old = json.load(open(path))
+        for label, syms in out.items():
+            old.setdefault(label, {}).update(syms)
+        out = old
+    json.dump(out, open(path, "w"), indent=1)
     print(json.dumps(out, indent=1))
 
 
