@@ -211,6 +211,15 @@ __device__ __forceinline__ void split2_f16(const u32x4 v, float s, uint2& h, uin
   l.y = cvt_pk_f16(f2 - a2, f3 - a3);
 }
 
+// eight fp32 values -> two fp16x8 pieces of s * v, in the bf16x8_t register type the fragment structs use
+__device__ __forceinline__ void split2x8(const f32x8 f, float s, bf16x8_t& h, bf16x8_t& l) {
+  uint2 h0, l0, h1, l1;
+  split2_f16(u32x4{__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3])}, s, h0, l0);
+  split2_f16(u32x4{__float_as_uint(f[4]), __float_as_uint(f[5]), __float_as_uint(f[6]), __float_as_uint(f[7])}, s, h1, l1);
+  h = __builtin_bit_cast(bf16x8_t, u32x4{h0.x, h0.y, h1.x, h1.y});
+  l = __builtin_bit_cast(bf16x8_t, u32x4{l0.x, l0.y, l1.x, l1.y});
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   static_assert(N >= 0 && N <= 63, "vmcnt immediate");
@@ -307,7 +316,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
   static_assert(!BPRE || (PREC == FCD_PREC_BF16X3 && BN % 16 == 0 && !N16), "BPRE shape");
   // BPRE: a B row is 3 planes x 4 chunks (32 bf16 each); one DMA instruction ("unit") covers 16 rows of
   // a plane; units past 3*BN/16 (BN = 64: 12 units on 8 waves) are all-out-of-range dummies
-  static_assert(NP == 3 || (NP == 2 && AH), "two planes (fp16 x 2) only in the A-halo form");
+  static_assert(NP == 3 || (NP == 2 && BPRE), "two planes (fp16 x 2): pre-split weights only");
   constexpr int BUNITS = NP * BN / 16;
   constexpr int AL = AH ? 0 : BM / RPI, BL = BPRE ? (BUNITS + NW - 1) / NW : BN / RPI;   // DMA instructions per wave per K-tile
   constexpr int AOFF = AH ? 0 : BM * 8;                            // float4 chunks of a stage's activation part
@@ -571,7 +580,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
         } else {
           const int r = wm * WTM + mi * 32 + lr, sw = (r >> 1) & 7;
           const float4 lo = As[r * 8 + (c0 ^ sw)], hi = As[r * 8 + ((c0 + 1) ^ sw)];
-          split3(f32x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w}, P.ah[mi], P.am[mi], P.al[mi]);
+          if constexpr (NP == 2) split2x8(f32x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w}, a_scale, P.ah[mi], P.al[mi]);
+          else split3(f32x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w}, P.ah[mi], P.am[mi], P.al[mi]);
         }
       }
 #pragma unroll
@@ -1405,7 +1415,8 @@ __device__ __forceinline__ unsigned plane_off(int row, int chunk, int row_bytes)
   return (unsigned)(row * row_bytes + 256 * (chunk >> 4) + 16 * ((chunk & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3))));
 }
 
-template <int BM, int WM, int WN>
+// NP = 2 (FCD_PREC_F16X2): two fp16 planes of the power-of-two-scaled operands, three fp16 MFMAs per product group.
+template <int BM, int WM, int WN, int NP = 3>
 __global__ __launch_bounds__(512) void conv_wgrad_x3p_kernel(const WgradArgs p, const size_t gs_bytes,
                                                              const size_t xb_bytes) {
   constexpr int BN = 128, KT = 32, NT = 512;
@@ -1415,7 +1426,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3p_kernel(const WgradArgs p, 
   constexpr int C4B = BN / 4, RPB = NT / C4B, BL = KT / RPB;
   constexpr int A_ROW = BM * 2, B_ROW = BN * 2;                  // bytes per plane row
   constexpr int A_PLANE = KT * A_ROW, B_PLANE = KT * B_ROW;
-  constexpr int STAGE = 3 * (A_PLANE + B_PLANE);
+  static_assert(NP == 2 || NP == 3, "planes");
+  constexpr int STAGE = NP * (A_PLANE + B_PLANE);
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1497,8 +1509,17 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3p_kernel(const WgradArgs p, 
 #pragma unroll
   for (int i = 0; i < AL; ++i) a_st[i] = plane_off(a_row + RPA * i, a_c4 >> 1, A_ROW) + 8 * (a_c4 & 1);
 #pragma unroll
-  for (int i = 0; i < BL; ++i) b_st[i] = 3 * A_PLANE + plane_off(b_row + RPB * i, b_c4 >> 1, B_ROW) + 8 * (b_c4 & 1);
-  auto split_store = [&](const u32x4 v, unsigned char* dst, int plane_bytes) {
+  for (int i = 0; i < BL; ++i) b_st[i] = NP * A_PLANE + plane_off(b_row + RPB * i, b_c4 >> 1, B_ROW) + 8 * (b_c4 & 1);
+  float sg = 1.f, sx = 1.f;
+  if constexpr (NP == 2) { sg = pow2_scale(p.g_amax); sx = pow2_scale(p.x_amax); }
+  auto split_store = [&](const u32x4 v, unsigned char* dst, int plane_bytes, float sc) {
+    if constexpr (NP == 2) {
+      uint2 h2, l2;
+      split2_f16(v, sc, h2, l2);
+      *reinterpret_cast<uint2*>(dst) = h2;
+      *reinterpret_cast<uint2*>(dst + plane_bytes) = l2;
+      return;
+    }
     const float f0 = __uint_as_float(v.x), f1 = __uint_as_float(v.y), f2 = __uint_as_float(v.z), f3 = __uint_as_float(v.w);
     const unsigned h0 = cvt_pk_bf16(f0, f1), h1 = cvt_pk_bf16(f2, f3);
     const float r0 = f0 - __uint_as_float(h0 << 16), r1 = f1 - __uint_as_float(h0 & 0xFFFF0000u);
@@ -1512,8 +1533,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3p_kernel(const WgradArgs p, 
     *reinterpret_cast<uint2*>(dst + 2 * plane_bytes) = make_uint2(l0, l1);
   };
   auto store_item = [&](int q_, unsigned char* base) {
-    if (q_ < AL) split_store(ra[q_], base + a_st[q_], A_PLANE);
-    else split_store(rb[q_ - AL], base + b_st[q_ - AL], B_PLANE);
+    if (q_ < AL) split_store(ra[q_], base + a_st[q_], A_PLANE, sg);
+    else split_store(rb[q_ - AL], base + b_st[q_ - AL], B_PLANE, sx);
   };
   auto store_tile = [&](int stg) {
     unsigned char* base = smem + stg * STAGE;
@@ -1535,7 +1556,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3p_kernel(const WgradArgs p, 
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni) {
       const int col = wn * WTN + ni * 32 + 16 * (g4 & 1) + 4 * pp;
-      b_rd[ni][j] = 3 * A_PLANE + plane_off(row, col >> 3, B_ROW) + 8 * ((col >> 2) & 1);
+      b_rd[ni][j] = NP * A_PLANE + plane_off(row, col >> 3, B_ROW) + 8 * ((col >> 2) & 1);
     }
   }
   auto frag = [&](const unsigned char* base, unsigned o0_, unsigned o1_) -> bf16x8_t {
@@ -1560,7 +1581,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3p_kernel(const WgradArgs p, 
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
-  constexpr int NI = AL + BL, NMF = 12 * TM * TN;      // items and MFMAs per K-tile
+  constexpr int NPR = NP == 3 ? 6 : 3;                 // products per group
+  constexpr int NI = AL + BL, NMF = 2 * NPR * TM * TN; // items and MFMAs per K-tile
   for (int it = 0; it < nk; ++it) {
     const unsigned char* cur = smem + (it & 1) * STAGE;
     unsigned char* nxt = smem + ((it + 1) & 1) * STAGE;
@@ -1576,30 +1598,41 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3p_kernel(const WgradArgs p, 
 #pragma unroll
       for (int mi = 0; mi < TM; ++mi) {
         ah[mi] = frag(ab, a_rd[mi][0], a_rd[mi][1]);
-        am[mi] = frag(ab + A_PLANE, a_rd[mi][0], a_rd[mi][1]);
-        al[mi] = frag(ab + 2 * A_PLANE, a_rd[mi][0], a_rd[mi][1]);
+        if constexpr (NP == 3) am[mi] = frag(ab + A_PLANE, a_rd[mi][0], a_rd[mi][1]);
+        al[mi] = frag(ab + (NP - 1) * A_PLANE, a_rd[mi][0], a_rd[mi][1]);
       }
 #pragma unroll
       for (int ni = 0; ni < TN; ++ni) {
         bh[ni] = frag(bb, b_rd[ni][0], b_rd[ni][1]);
-        bm2[ni] = frag(bb + B_PLANE, b_rd[ni][0], b_rd[ni][1]);
-        bl[ni] = frag(bb + 2 * B_PLANE, b_rd[ni][0], b_rd[ni][1]);
+        if constexpr (NP == 3) bm2[ni] = frag(bb + B_PLANE, b_rd[ni][0], b_rd[ni][1]);
+        bl[ni] = frag(bb + (NP - 1) * B_PLANE, b_rd[ni][0], b_rd[ni][1]);
       }
 #pragma unroll
-      for (int pc = 0; pc < 6; ++pc)
+      for (int pc = 0; pc < NPR; ++pc)
 #pragma unroll
         for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
           for (int ni = 0; ni < TN; ++ni) {
-            const bf16x8_t a = pc == 0 ? al[mi] : (pc == 2 || pc == 3) ? am[mi] : ah[mi];
-            const bf16x8_t b = pc == 1 ? bl[ni] : (pc == 2 || pc == 4) ? bm2[ni] : bh[ni];
-            if (pc < 5) acc2[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc2[mi][ni], 0, 0, 0);
-            else acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[mi][ni], 0, 0, 0);
-            const int g = ((s2 * 6 + pc) * TM + mi) * TN + ni;       // 0 .. NMF-1
+            if constexpr (NP == 2) {
+              // al.bh, ah.bl into the side accumulator, ah.bh into the main one
+              const f16x8_t a = __builtin_bit_cast(f16x8_t, pc == 0 ? al[mi] : ah[mi]);
+              const f16x8_t b = __builtin_bit_cast(f16x8_t, pc == 1 ? bl[ni] : bh[ni]);
+              if (pc < 2) acc2[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc2[mi][ni], 0, 0, 0);
+              else acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[mi][ni], 0, 0, 0);
+            } else {
+              const bf16x8_t a = pc == 0 ? al[mi] : (pc == 2 || pc == 3) ? am[mi] : ah[mi];
+              const bf16x8_t b = pc == 1 ? bl[ni] : (pc == 2 || pc == 4) ? bm2[ni] : bh[ni];
+              if (pc < 5) acc2[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc2[mi][ni], 0, 0, 0);
+              else acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[mi][ni], 0, 0, 0);
+            }
+            const int g = ((s2 * NPR + pc) * TM + mi) * TN + ni;     // 0 .. NMF-1
 #pragma unroll
             for (int q_ = 0; q_ < NI; ++q_) {
+              // (the last load slot is clamped: with 6 MFMAs and 3 items per K-tile -- NP = 2, BM = 64 -- it would fall
+              // past the end, and the item's register would never be refilled)
+              constexpr int LD_OFF = NMF / (2 * NI) + 1;
               if (q_ * NMF / NI + 1 == g) store_item(q_, nxt);
-              if (q_ * NMF / NI + NMF / (2 * NI) + 1 == g) load_item(q_);
+              if ((q_ * NMF / NI + LD_OFF < NMF ? q_ * NMF / NI + LD_OFF : NMF - 1) == g) load_item(q_);
             }
           }
     }
@@ -1612,6 +1645,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3p_kernel(const WgradArgs p, 
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] += acc2[i][j][r];
+  const float isc = NP == 2 ? (1.f / sg) * (1.f / sx) : 1.f;     // powers of two: exact
   // D[row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)][col = lane&31] of sub-tile (mi, ni)
   float* __restrict__ dst = p.slab + (long)ks * p.O * p.ND;
   const int lr = lane & 31, lh = lane >> 5;
@@ -1624,7 +1658,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3p_kernel(const WgradArgs p, 
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int o = tm * BM + wm * WTM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (o < p.O) dst[(long)o * p.ND + col] = acc[mi][ni][r];
+        if (o < p.O) dst[(long)o * p.ND + col] = acc[mi][ni][r] * isc;
       }
     }
 }
@@ -2753,19 +2787,32 @@ __global__ __launch_bounds__(256) void pack_fwd_h2_kernel(const float* __restric
     store_split2(out, total, idx, i < I ? sc * w[((long)o * I + i) * taps + tap] : 0.f);
   }
 }
-// stride 1 only: out[plane][i][th][tw][o], taps flipped
+// out[phase][plane][i][th][tw][o], element order of pack_adj_x3_kernel
 __global__ __launch_bounds__(256) void pack_adj_h2_kernel(const float* __restrict__ w, unsigned short* __restrict__ out,
-                                                          int O, int OP, int I, int KH, int KW, const float* __restrict__ amax) {
+                                                          int O, int OP, int I, int KH, int KW, int stride,
+                                                          const float* __restrict__ amax) {
   const float sc = pow2_scale(amax);
-  const long total = (long)I * KH * KW * OP;
+  const int TH = stride == 1 ? KH : 2, TW = stride == 1 ? KW : 2;
+  const int nph = stride == 1 ? 1 : 4;
+  const long per_phase = (long)I * TH * TW * OP;
+  const long total = (long)nph * per_phase;
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
     const int o = (int)(idx % OP);
     long t = idx / OP;
-    const int tw = (int)(t % KW); t /= KW;
-    const int th = (int)(t % KH); t /= KH;
-    const int i = (int)t;
-    const int kh = KH - 1 - th, kw = KW - 1 - tw;
-    store_split2(out, total, idx, o < O ? sc * w[(((long)o * I + i) * KH + kh) * KW + kw] : 0.f);
+    const int tw = (int)(t % TW); t /= TW;
+    const int th = (int)(t % TH); t /= TH;
+    const int i = (int)(t % I);
+    const int ph = (int)(t / I);
+    int kh, kw;
+    if (stride == 1) {
+      kh = KH - 1 - th;
+      kw = KW - 1 - tw;
+    } else {
+      kh = 3 - (ph >> 1) - 2 * th;
+      kw = 3 - (ph & 1) - 2 * tw;
+    }
+    store_split2(out + (long)ph * 2 * per_phase, per_phase, idx - (long)ph * per_phase,
+                 o < O ? sc * w[(((long)o * I + i) * KH + kh) * KW + kw] : 0.f);
   }
 }
 
@@ -3013,47 +3060,38 @@ int run_gather(const FcdConvDesc* d, GatherArgs& a, hipStream_t st) {
   if (wants_split_weights(d)) {
     a.tiles_m = fcd_cdiv(a.M, 128);
     a.tiles_n = fcd_cdiv(d->Cout, bn);
-    a.w_phase_stride = (long)d->Cout * a.K * 3 / 2;      // three bf16 planes, in units of 4 bytes
+    const bool h2 = a.a_amax != nullptr;                 // FCD_PREC_F16X2: two fp16 planes instead of three bf16 ones
+    a.w_phase_stride = h2 ? (long)d->Cout * a.K : (long)d->Cout * a.K * 3 / 2;      // in units of 4 bytes
     dim3 grid(a.tiles_m * a.tiles_n, a.nphase * a.splitk);
     const size_t in_bytes = (size_t)a.N * a.IH * a.IW * a.Cin * 4;
-    const unsigned w_bytes = (unsigned)((size_t)a.Cout * a.K * 6);
+    const unsigned w_bytes = (unsigned)((size_t)a.Cout * a.K * (h2 ? 4 : 6));
+    constexpr int X3 = FCD_PREC_BF16X3;
+#define FCD_LAUNCH_PRESPLIT(BM_, BN_, WM_, WN_, S_, AH_)                                                                       \
+  do {                                                                                                                        \
+    if (h2) {                                                                                                                 \
+      note_kernel("conv_gather_dma_kernel<%d, %d, %d, %d, %d, 2, false, true, %s, 2>", BM_, BN_, WM_, WN_, S_, AH_ ? "true" : "false"); \
+      hipLaunchKernelGGL((conv_gather_dma_kernel<BM_, BN_, WM_, WN_, S_, X3, false, true, AH_, 2>), grid, dim3(512), 0, st, a, \
+                         in_bytes, w_bytes);                                                                                  \
+    } else {                                                                                                                  \
+      note_kernel("conv_gather_dma_kernel<%d, %d, %d, %d, %d, 2, false, true, %s, 3>", BM_, BN_, WM_, WN_, S_, AH_ ? "true" : "false"); \
+      hipLaunchKernelGGL((conv_gather_dma_kernel<BM_, BN_, WM_, WN_, S_, X3, false, true, AH_, 3>), grid, dim3(512), 0, st, a, \
+                         in_bytes, w_bytes);                                                                                  \
+    }                                                                                                                         \
+  } while (0)
     if (gather_big_tile(d)) {
       a.tiles_m = fcd_cdiv(a.M, 256);
       grid = dim3(a.tiles_m * a.tiles_n, a.nphase * a.splitk);
-      note_kernel(bn == 128 ? "conv_gather_dma_kernel<256, 128, 4, 2, 2, 2, false, true>"
-                            : "conv_gather_dma_kernel<256, 64, 8, 1, 3, 2, false, true>");
-      if (gather_ahalo(d, 256) && a.a_amax) {
-        note_kernel("conv_gather_dma_kernel<256, 128, 4, 2, 3, 2, false, true, true, 2>");
-        hipLaunchKernelGGL((conv_gather_dma_kernel<256, 128, 4, 2, 3, FCD_PREC_BF16X3, false, true, true, 2>), grid, dim3(512), 0, st,
-                           a, in_bytes, (unsigned)((size_t)a.Cout * a.K * 4));
-      } else if (gather_ahalo(d, 256)) {
-        note_kernel("conv_gather_dma_kernel<256, 128, 4, 2, 3, 2, false, true, true>");
-        hipLaunchKernelGGL((conv_gather_dma_kernel<256, 128, 4, 2, 3, FCD_PREC_BF16X3, false, true, true>), grid, dim3(512), 0, st,
-                           a, in_bytes, w_bytes);
-      } else if (bn == 128)
-        hipLaunchKernelGGL((conv_gather_dma_kernel<256, 128, 4, 2, 2, FCD_PREC_BF16X3, false, true>), grid, dim3(512), 0, st, a,
-                           in_bytes, w_bytes);
-      else
-        hipLaunchKernelGGL((conv_gather_dma_kernel<256, 64, 8, 1, 3, FCD_PREC_BF16X3, false, true>), grid, dim3(512), 0, st, a,
-                           in_bytes, w_bytes);
-    } else if (bn == 128 && gather_ahalo(d, 128) && a.a_amax) {
-      a.w_phase_stride = (long)d->Cout * a.K;              // two fp16 planes, in units of 4 bytes
-      note_kernel("conv_gather_dma_kernel<128, 128, 4, 2, 3, 2, false, true, true, 2>");
-      hipLaunchKernelGGL((conv_gather_dma_kernel<128, 128, 4, 2, 3, FCD_PREC_BF16X3, false, true, true, 2>), grid, dim3(512), 0, st, a,
-                         in_bytes, (unsigned)((size_t)a.Cout * a.K * 4));
+      if (gather_ahalo(d, 256)) FCD_LAUNCH_PRESPLIT(256, 128, 4, 2, 3, true);
+      else if (bn == 128) FCD_LAUNCH_PRESPLIT(256, 128, 4, 2, 2, false);
+      else FCD_LAUNCH_PRESPLIT(256, 64, 8, 1, 3, false);
     } else if (bn == 128 && gather_ahalo(d, 128)) {
-      note_kernel("conv_gather_dma_kernel<128, 128, 4, 2, 3, 2, false, true, true>");
-      hipLaunchKernelGGL((conv_gather_dma_kernel<128, 128, 4, 2, 3, FCD_PREC_BF16X3, false, true, true>), grid, dim3(512), 0, st, a,
-                         in_bytes, w_bytes);
+      FCD_LAUNCH_PRESPLIT(128, 128, 4, 2, 3, true);
     } else if (bn == 128) {
-      note_kernel("conv_gather_dma_kernel<128, 128, 4, 2, 3, 2, false, true>");
-      hipLaunchKernelGGL((conv_gather_dma_kernel<128, 128, 4, 2, 3, FCD_PREC_BF16X3, false, true>), grid, dim3(512), 0, st, a,
-                         in_bytes, w_bytes);
+      FCD_LAUNCH_PRESPLIT(128, 128, 4, 2, 3, false);
     } else {
-      note_kernel("conv_gather_dma_kernel<128, 64, 4, 2, 3, 2, false, true>");
-      hipLaunchKernelGGL((conv_gather_dma_kernel<128, 64, 4, 2, 3, FCD_PREC_BF16X3, false, true>), grid, dim3(512), 0, st, a,
-                         in_bytes, w_bytes);
+      FCD_LAUNCH_PRESPLIT(128, 64, 4, 2, 3, false);
     }
+#undef FCD_LAUNCH_PRESPLIT
     rc = fcd_check_launch("conv_gather");
     if (rc) return rc;
     if (a.splitk > 1) {
@@ -3102,8 +3140,10 @@ int fused_stats_chunks(const FcdConvDesc* d) {
   return (int)(d->nphase * (ghw / wtm));
 }
 
-// FCD_PREC_F16X2 exists only as the two-plane A-halo form; every other shape under it runs as FCD_PREC_BF16X3.  The
-// public entry points work on a normalised copy of the descriptor (precision BF16X3) plus this flag.
+// FCD_PREC_F16X2 exists as the two-plane form of the kernels that take pre-split weights (format 1 under BF16X3: the
+// A-halo form and the per-tap gather form, which splits its activation fragments in registers); every other shape
+// under it runs as FCD_PREC_BF16X3.  The public entry points work on a normalised copy of the descriptor (precision
+// BF16X3) plus this flag.
 struct NormDesc {
   FcdConvDesc d;
   bool h2;
@@ -3117,7 +3157,7 @@ NormDesc normalise(const FcdConvDesc* d) {
     if (validate_conv(&n.d) == FCD_OK && wants_split_weights(&n.d)) {
       int bm, bn;
       gather_tile(&n.d, bm, bn);
-      n.h2 = gather_big_tile(&n.d) ? gather_ahalo(&n.d, 256) : (bn == 128 && gather_ahalo(&n.d, 128));
+      n.h2 = true;       // every pre-split (format 1) shape has a two-plane form
     }
   }
   return n;
@@ -3320,8 +3360,10 @@ extern "C" int fcd_conv_wgrad(const FcdWgradDesc* d, const float* gsmall, const 
                               void* workspace, size_t workspace_bytes, void* stream) {
   FCD_REQUIRE(d != nullptr, "wgrad: null descriptor");
   FcdWgradDesc dd = *d;
-  const bool want_h2 = d->precision == FCD_PREC_F16X2;
-  if (want_h2) dd.precision = FCD_PREC_BF16X3;
+  // FCD_PREC_F16X2: the two-plane forms need both maxima; without them (and for the shapes that have no such form)
+  // the weight gradient runs as FCD_PREC_BF16X3 -- unlike the convolutions there is no operand format tied to the choice
+  const bool want_h2 = d->precision == FCD_PREC_F16X2 && d->g_amax && d->x_amax;
+  if (d->precision == FCD_PREC_F16X2) dd.precision = FCD_PREC_BF16X3;
   const float* g_amax = want_h2 ? d->g_amax : nullptr;
   const float* x_amax = want_h2 ? d->x_amax : nullptr;
   d = &dd;
@@ -3373,7 +3415,6 @@ extern "C" int fcd_conv_wgrad(const FcdWgradDesc* d, const float* gsmall, const 
     const int ncb = d->IP / 64;
     dim3 grid((d->OP / 64) * ncb, slabs3);
     if (want_h2) {
-      FCD_REQUIRE(g_amax && x_amax, "wgrad: FCD_PREC_F16X2 needs g_amax and x_amax");
       a.g_amax = g_amax; a.x_amax = x_amax;
       note_kernel("wgrad3_halo_x3_kernel<2>");
       hipLaunchKernelGGL(wgrad3_halo_x3_kernel<2>, grid, dim3(64 * W3_WAVES), 0, st, a, ipS, ncb,
@@ -3408,10 +3449,18 @@ extern "C" int fcd_conv_wgrad(const FcdWgradDesc* d, const float* gsmall, const 
     a.tiles_m = fcd_cdiv(d->O, bm); a.tiles_n = fcd_cdiv(a.ND, 128);
     dim3 grid(a.tiles_m * a.tiles_n, a.splitk);
     const size_t gsb = (size_t)a.P * a.OP * 4, xbb = (size_t)a.N * a.BH * a.BW * a.IP * 4;
-    note_kernel("conv_wgrad_x3p_kernel<%d, %d, %d>", bm, bm == 64 ? 2 : 4, bm == 64 ? 4 : 2);
-    if (bm == 64) hipLaunchKernelGGL((conv_wgrad_x3p_kernel<64, 2, 4>), grid, dim3(512), 0, st, a, gsb, xbb);
-    else if (bm == 128) hipLaunchKernelGGL((conv_wgrad_x3p_kernel<128, 4, 2>), grid, dim3(512), 0, st, a, gsb, xbb);
-    else hipLaunchKernelGGL((conv_wgrad_x3p_kernel<256, 4, 2>), grid, dim3(512), 0, st, a, gsb, xbb);
+    if (want_h2) {
+      a.g_amax = g_amax; a.x_amax = x_amax;
+      note_kernel("conv_wgrad_x3p_kernel<%d, %d, %d, 2>", bm, bm == 64 ? 2 : 4, bm == 64 ? 4 : 2);
+      if (bm == 64) hipLaunchKernelGGL((conv_wgrad_x3p_kernel<64, 2, 4, 2>), grid, dim3(512), 0, st, a, gsb, xbb);
+      else if (bm == 128) hipLaunchKernelGGL((conv_wgrad_x3p_kernel<128, 4, 2, 2>), grid, dim3(512), 0, st, a, gsb, xbb);
+      else hipLaunchKernelGGL((conv_wgrad_x3p_kernel<256, 4, 2, 2>), grid, dim3(512), 0, st, a, gsb, xbb);
+    } else {
+      note_kernel("conv_wgrad_x3p_kernel<%d, %d, %d, 3>", bm, bm == 64 ? 2 : 4, bm == 64 ? 4 : 2);
+      if (bm == 64) hipLaunchKernelGGL((conv_wgrad_x3p_kernel<64, 2, 4, 3>), grid, dim3(512), 0, st, a, gsb, xbb);
+      else if (bm == 128) hipLaunchKernelGGL((conv_wgrad_x3p_kernel<128, 4, 2, 3>), grid, dim3(512), 0, st, a, gsb, xbb);
+      else hipLaunchKernelGGL((conv_wgrad_x3p_kernel<256, 4, 2, 3>), grid, dim3(512), 0, st, a, gsb, xbb);
+    }
     rc = fcd_check_launch("conv_wgrad");
   } else if (d->O <= 64) {
     a.tiles_m = fcd_cdiv(d->O, 64); a.tiles_n = fcd_cdiv(a.ND, 128);
@@ -3525,12 +3574,14 @@ extern "C" int fcd_pack_weight_fwd_h2(const float* w, void* packed, const float*
 }
 
 extern "C" int fcd_pack_weight_adj_h2(const float* w, void* packed, const float* w_amax, int O, int OP, int I, int KH, int KW,
-                                      void* stream) {
+                                      int stride, void* stream) {
   FCD_REQUIRE(w && packed && w_amax && O > 0 && I > 0 && OP >= O && OP % 4 == 0 && KH > 0 && KW > 0, "pack_weight_adj_h2: bad arguments");
-  const long total = (long)I * KH * KW * OP;
+  FCD_REQUIRE((stride == 1) || (stride == 2 && KH == 4 && KW == 4), "pack_weight_adj_h2: unsupported stride/kernel");
+  const int TH = stride == 1 ? KH : 2, TW = stride == 1 ? KW : 2, nph = stride == 1 ? 1 : 4;
+  const long total = (long)nph * I * TH * TW * OP;
   const int blocks = (int)std::min<long>(fcd_cdiv(total, 256), 4096);
   hipLaunchKernelGGL(pack_adj_h2_kernel, dim3(blocks), dim3(256), 0, fcd_stream(stream), w, (unsigned short*)packed, O, OP, I,
-                     KH, KW, w_amax);
+                     KH, KW, stride, w_amax);
   return fcd_check_launch("pack_weight_adj_h2");
 }
 

@@ -401,24 +401,26 @@ class _GeneratorFn(torch.autograd.Function):
             else:
                 dz = g
                 dz_ok = False
-            h2_layer = h2 and ly.kind == "conv" and gm.k == 3 and gm.s == 1     # the layers PREC_F16X2 kernels exist for
-
             def dz_amax():
                 nonlocal dz_ok
                 if not dz_ok:
                     ops.absmax(dz, out=gmx[li])
                     dz_ok = True
                 return gmx[li]
-            # weight gradient
+            # weight gradient (PREC_F16X2: the kernels with a two-plane form want max |.| of both operands; the 7x7
+            # image layers' kernels run as BF16X3 and ignore them)
+            h2_w = h2 and prec_w == L.PREC_F16X2 and gm.k != 7
             if needs[p0]:
                 sink = grad_sink(ly.conv.weight, True)     # arena-backed: accumulate into p.grad in place
                 if ly.kind == "conv":
                     wd = gm.wgrad_desc(n, a_in.shape[1], a_in.shape[2], precision=prec_w, accumulate=sink is not None)
-                    if h2_layer and prec_w == L.PREC_F16X2:
+                    if h2_w:
                         ops.set_wgrad_amax(wd, dz_amax(), act_amax(li))
                     dw = ops.conv_wgrad(wd, dz, a_in, dw=sink)
                 else:
                     wd = gm.wgrad_desc(n, dz.shape[1], dz.shape[2], precision=prec_w, accumulate=sink is not None)
+                    if h2_w:
+                        ops.set_wgrad_amax(wd, act_amax(li), dz_amax())
                     dw = ops.conv_wgrad(wd, a_in, dz, dw=sink)
                 if sink is None:
                     grads[p0] = dw
@@ -428,7 +430,10 @@ class _GeneratorFn(torch.autograd.Function):
             if li == 0:
                 if need_x:
                     d = gm.adj_desc(n, dz.shape[1], dz.shape[2], precision=prec)
-                    g0 = ops.conv_gather(d, dz, ly.conv.operand("adj", gm, d))
+                    wa = ly.conv.operand("adj", gm, d)
+                    if h2 and d.w_amax:
+                        d.a_amax = dz_amax().data_ptr()
+                    g0 = ops.conv_gather(d, dz, wa)
                     ops.nhwc_to_nchw(g0, x.shape[1], out=gx, accumulate=True)
                 break
             res = pending_res.pop(li, None)
@@ -440,6 +445,9 @@ class _GeneratorFn(torch.autograd.Function):
                 g = ops.conv_gather(d, dz, wa, residual=res)
             else:
                 d = gm.fwd_desc(n, dz.shape[1], dz.shape[2], precision=prec)
-                g = ops.conv_gather(d, dz, ly.conv.operand("fwd", gm, d), residual=res)
+                wa = ly.conv.operand("fwd", gm, d)
+                if h2 and d.w_amax:
+                    d.a_amax = dz_amax().data_ptr()
+                g = ops.conv_gather(d, dz, wa, residual=res)
         ctx.acts = ctx.saved_layers = None
         return (None, gx, None) + tuple(grads)

@@ -300,10 +300,10 @@ def pack_weight_fwd_h2(w: torch.Tensor, g: ConvGeom, w_amax: torch.Tensor) -> to
 
 def pack_weight_adj_h2(w: torch.Tensor, g: ConvGeom, w_amax: torch.Tensor) -> torch.Tensor:
     L.require_gpu_tensor(w, "weight")
-    if g.s != 1:
-        raise NotImplementedError("pack_weight_adj_h2: stride 1 only")
-    out = torch.empty((2, g.I, g.k, g.k, g.OP), dtype=torch.float16, device=w.device)
-    check(L.load().fcd_pack_weight_adj_h2(ptr(w), ptr(out), ptr(w_amax), g.O, g.OP, g.I, g.k, g.k, stream()), "pack_weight_adj_h2")
+    t = g.adj_taps()
+    out = torch.empty((g.adj_phases(), 2, g.I, t, t, g.OP), dtype=torch.float16, device=w.device)
+    check(L.load().fcd_pack_weight_adj_h2(ptr(w), ptr(out), _amax_ptr(w_amax), g.O, g.OP, g.I, g.k, g.k, g.s, stream()),
+          "pack_weight_adj_h2")
     return out
 
 

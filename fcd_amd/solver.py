@@ -207,11 +207,15 @@ class FCDSolver(nn.Module):
         into three bf16 pieces (exactly, up to 2^-24), six bf16 MFMAs per product group, fp32
         accumulate; measured error against fp64 no larger than the exact-fp32 MFMA's, convolutions
         20-40 % faster.  The 10/12-channel image layers keep their exact-fp32 16-wide kernels.
+        'fp32x2': as fp32x3, but the generator's convolutions that take pre-split weights (and the weight gradient of
+        its 3x3 layers) split each operand, scaled by a power of two taken from the tensor's max |.|, into two fp16
+        pieces: three MFMAs per product group instead of six, same parity bars.  The maxima come from the kernels
+        that write the operands (InstanceNorm apply / backward).  The discriminator runs as under fp32x3.
         'bf16': operands rounded to bf16, fp32 accumulate."""
         p, pw = {"fp32": (L.PREC_F32, None), "fp32x3": (L.PREC_BF16X3, None), "bf16": (L.PREC_BF16, None),
                  "fp32x2": (L.PREC_F16X2, None)}[precision]
         for net in (self.G, self.D):
-            net.precision = p
+            net.precision = L.PREC_BF16X3 if (p == L.PREC_F16X2 and net is self.D) else p
             net.wgrad_precision = pw
             for m in net.modules():          # drop packed weights of the other precision's layout
                 if hasattr(m, "_packed"):

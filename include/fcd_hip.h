@@ -43,9 +43,9 @@ extern "C" {
 #define FCD_PREC_BF16X3 2 /* each fp32 operand split into three bf16 pieces in registers, six bf16 MFMAs
                              per product group, fp32 accumulate: fp32-faithful at the bf16 matrix rate */
 #define FCD_AMAX_SLOTS 1024 /* an "amax" scalar of FCD_PREC_F16X2 is an array of 1024 floats (one per producing block) whose maximum is the value */
-#define FCD_PREC_F16X2 3  /* 3x3 stride-1 layers that take the A-halo kernel: each fp32 operand scaled by a power of two and
-                             split into two fp16 pieces, three fp16 MFMAs (22+ operand bits; fp32 accumulate); every
-                             other shape runs as FCD_PREC_BF16X3.  Needs FcdConvDesc.a_amax / w_amax.                */
+#define FCD_PREC_F16X2 3  /* convolutions that take pre-split weights (fcd_conv_weight_format 2): each fp32 operand scaled by
+                             a power of two and split into two fp16 pieces, three fp16 MFMAs (22+ operand bits; fp32
+                             accumulate); every other shape runs as FCD_PREC_BF16X3.  Needs FcdConvDesc.a_amax / w_amax. */
 
 /* activation codes accepted where an InstanceNorm entry point takes `act_slope` (values outside [0,1]) */
 #define FCD_ACT_SILU 2.0f
@@ -144,15 +144,15 @@ int fcd_pack_weight_adj(const float* w, float* packed, int O, int OP, int I, int
  * bf16 (6 bytes per weight).  Elsewhere BF16X3 takes the fp32 packs and splits in registers. */
 int fcd_conv_wants_split_weights(const FcdConvDesc* d);
 /* Weight operand the convolution described by d takes: 0 = fp32 packs (fcd_pack_weight_fwd / _adj), 1 = three bf16
- * planes (_x3), 2 = two fp16 planes of the scaled weights (_h2; FCD_PREC_F16X2 where the A-halo kernel applies).
+ * planes (_x3), 2 = two fp16 planes of the scaled weights (_h2; FCD_PREC_F16X2 wherever BF16X3 would take format 1).
  * No reference counterpart (cuDNN chooses its own operand formats). */
 int fcd_conv_weight_format(const FcdConvDesc* d);
 /* FCD_PREC_F16X2 weight operands: [plane h | plane l][row][K] fp16 of s*w, s the power of two derived from *w_amax
- * (device scalar, max |w|), element orders as fcd_pack_weight_fwd / _adj (stride 1). */
+ * (device scalar, max |w|), element orders as fcd_pack_weight_fwd / _adj ([phase][plane]... for the adjoint form). */
 int fcd_pack_weight_fwd_h2(const float* w, void* packed, const float* w_amax, int O, int I, int IP, int KH, int KW,
                            void* stream);
 int fcd_pack_weight_adj_h2(const float* w, void* packed, const float* w_amax, int O, int OP, int I, int KH, int KW,
-                           void* stream);
+                           int stride, void* stream);
 int fcd_pack_weight_fwd_x3(const float* w, void* packed, int O, int I, int IP, int KH, int KW,
                            void* stream);
 int fcd_pack_weight_adj_x3(const float* w, void* packed, int O, int OP, int I, int KH, int KW,

@@ -441,11 +441,11 @@ def test_gather_a_halo_equals_per_tap_gather(dev, geom, monkeypatch):
         cref = I
         stats = None
     new = run().clone()
-    assert L.load().fcd_last_conv_kernel().endswith(b"true, true>")
+    assert L.load().fcd_last_conv_kernel().endswith(b"true, true, 3>")
     st_new = [t.clone() for t in stats()] if stats else None
     monkeypatch.setenv("FCD_NO_HALO3", "1")
     old = run().clone()
-    assert not L.load().fcd_last_conv_kernel().endswith(b"true, true>")
+    assert not L.load().fcd_last_conv_kernel().endswith(b"true, true, 3>")
     st_old = [t.clone() for t in stats()] if stats else None
     monkeypatch.delenv("FCD_NO_HALO3")
     assert torch.equal(new, old)
@@ -575,9 +575,36 @@ def test_wgrad3_halo_f16x2(dev, shape):
     d2 = ops.set_wgrad_amax(g.wgrad_desc(n, h, 32, precision=L.PREC_F16X2, accumulate=True), ops.absmax(gd), ops.absmax(xd))
     ops.conv_wgrad(d2, gd, xd, dw=acc)
     assert relerr(acc.cpu() - base, ref) <= 1e-5
-    # without the maxima the launch is refused (no guessed scale)
-    with pytest.raises(RuntimeError):
-        ops.conv_wgrad(g.wgrad_desc(n, h, 32, precision=L.PREC_F16X2), gd, xd)
+    # without the maxima the same descriptor runs the BF16X3 form
+    dw3 = ops.conv_wgrad(g.wgrad_desc(n, h, 32, precision=L.PREC_F16X2), gd, xd)
+    assert L.load().fcd_last_conv_kernel() == b"wgrad3_halo_x3_kernel"
+    assert relerr(dw3.cpu(), ref) <= 1e-6
+
+
+@pytest.mark.parametrize("shape", [(128, 64, 6, 32, 32, 1.0, 3e-4), (256, 128, 5, 16, 16, 40.0, 1.0),
+                                   (128, 256, 3, 16, 16, 1e-3, 1.0), (96, 64, 2, 24, 40, 1.0, 1.0), (48, 24, 2, 16, 16, 1.0, 1.0),
+                                   (64, 64, 7, 8, 8, 5.0, 0.1)])
+def test_wgrad_x3p_f16x2(dev, shape):
+    """FCD_PREC_F16X2 weight gradient of the 4x4 stride-2 layers (conv_wgrad_x3p_kernel<.., 2>: operands split once per
+    workgroup into two fp16 planes of the scaled values): <= 1e-6 of max |dW| from torch in float64 across operand
+    magnitudes, ragged channel counts and accumulation."""
+    from fcd_amd import _lib as L, ops
+    O, I, n, h, w, sg, sx = shape
+    g = ops.ConvGeom(O, I, 4, 2, 1)
+    gen = torch.Generator().manual_seed(29)
+    big = torch.randn(n, I, 2 * h, 2 * w, generator=gen) * sx
+    small = torch.randn(n, O, h, w, generator=gen) * sg
+    bd, sd = to_nhwc(big, g.IP).to(dev), to_nhwc(small, g.OP).to(dev)
+    d = ops.set_wgrad_amax(g.wgrad_desc(n, 2 * h, 2 * w, precision=L.PREC_F16X2), ops.absmax(sd), ops.absmax(bd))
+    dw = ops.conv_wgrad(d, sd, bd)
+    assert L.load().fcd_last_conv_kernel().startswith(b"conv_wgrad_x3p_kernel") and L.load().fcd_last_conv_kernel().endswith(b", 2>")
+    ref = torch.nn.grad.conv2d_weight(big.double(), (O, I, 4, 4), small.double(), stride=2, padding=1)
+    assert relerr(dw.cpu(), ref) <= 1e-6
+    base = float(ref.abs().max()) * 0.5
+    acc = torch.full_like(dw, base)
+    d2 = ops.set_wgrad_amax(g.wgrad_desc(n, 2 * h, 2 * w, precision=L.PREC_F16X2, accumulate=True), ops.absmax(sd), ops.absmax(bd))
+    ops.conv_wgrad(d2, sd, bd, dw=acc)
+    assert relerr(acc.cpu() - base, ref) <= 1e-5
 
 
 def test_absmax_and_norm_amax(dev):
@@ -604,3 +631,52 @@ def test_absmax_and_norm_amax(dev):
         assert float(gm.max()) == float(dz.abs().max())
         dz0, _, _ = ops.instnorm_bwd(gy, y, z, mean, rstd, gamma, 0.0, False)
         assert torch.equal(dz, dz0)
+
+
+# (O, I, N, small H, small W, form, operand scale): 4x4 stride-2 layers of the generator (down / up sampling)
+H2_S2_GEOMS = [
+    (128, 64, 8, 32, 32, "fwd", 1.0),        # 128-row tiles, 64 input channels
+    (256, 128, 32, 16, 16, "fwd", 2e-4),     # 256 x 128 tiles
+    (256, 128, 9, 16, 16, "adj", 50.0),      # four phases, 128 output channels
+    (128, 64, 33, 32, 32, "adj", 1.0),       # 256 x 64 tiles (8 x 1 waves), ragged last tile
+]
+
+
+@pytest.mark.parametrize("geom", H2_S2_GEOMS)
+def test_gather_per_tap_f16x2(dev, geom):
+    """FCD_PREC_F16X2 in the per-tap gather form (every shape that takes pre-split weights under BF16X3): activation
+    fragments scaled and split into two fp16 pieces in registers, weights as two fp16 planes ([phase][plane] for the
+    four-phase adjoint of a stride-2 layer); <= 1e-6 of max |result| from torch in float64, with the epilogue operands
+    and the fused InstanceNorm statistics."""
+    from fcd_amd import _lib as L, ops
+    O, I, N, H, W, form, sc = geom
+    g = ops.ConvGeom(O, I, 4, 2, 1)
+    gen = torch.Generator().manual_seed(31)
+    wt = torch.randn(O, I, 4, 4, generator=gen) / (4 * I ** 0.5)
+    wd = wt.to(dev)
+    wa = ops.absmax(wd)
+    if form == "fwd":
+        x = torch.randn(N, I, 2 * H, 2 * W, generator=gen) * sc
+        xd = to_nhwc(x, g.IP).to(dev)
+        d = g.fwd_desc(N, 2 * H, 2 * W, precision=L.PREC_F16X2)
+        assert ops.weight_format(d) == 2
+        ops.set_amax(d, ops.absmax(xd), wa)
+        wp = ops.pack_weight_fwd_h2(wd, g, wa)
+        z, mean, rstd, varu = ops.conv_gather_stats(d, xd, wp, want_var=True)
+        ref = F.conv2d(x.double(), wt.double(), None, 2, 1)
+        assert relerr(from_nhwc(z.cpu(), O).double(), ref) <= 1e-6
+        assert relerr(mean.cpu().double(), ref.mean(dim=(2, 3))) <= 1e-5
+        assert relerr(varu.cpu().double(), ref.var(dim=(2, 3), unbiased=True)) <= 1e-5
+    else:
+        gy = torch.randn(N, O, H, W, generator=gen) * sc
+        mask = torch.randn(N, I, 2 * H, 2 * W, generator=gen)
+        res = torch.randn(N, I, 2 * H, 2 * W, generator=gen) * sc
+        gd, md, rd = to_nhwc(gy, g.OP).to(dev), to_nhwc(mask, g.IP).to(dev), to_nhwc(res, g.IP).to(dev)
+        d = g.adj_desc(N, H, W, precision=L.PREC_F16X2, mask_slope=0.2)
+        assert ops.weight_format(d) == 2
+        ops.set_amax(d, ops.absmax(gd), wa)
+        wp = ops.pack_weight_adj_h2(wd, g, wa)
+        got = ops.conv_gather(d, gd, wp, mask=md, residual=rd)
+        ref = F.conv_transpose2d(gy.double(), wt.double(), None, 2, 1) * torch.where(mask > 0, 1.0, 0.2) + res
+        assert relerr(from_nhwc(got.cpu(), I).double(), ref) <= 1e-6
+    assert L.load().fcd_last_conv_kernel().endswith(b"false, 2>")
