@@ -8,11 +8,12 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def test_stress_config_properties(dev):
+@pytest.mark.parametrize("mode", ["fp32x3", "fp32x2"])
+def test_stress_config_properties(dev, mode):
     from fcd_amd import FCDSolver
     from fcd_amd.synth import synth_batch
     torch.manual_seed(5)
-    s = FCDSolver(None, image_size=256, g_conv_dim=128, d_conv_dim=128, batch_size=32, precision="fp32x3").to(dev)
+    s = FCDSolver(None, image_size=256, g_conv_dim=128, d_conv_dim=128, batch_size=32, precision=mode).to(dev)
     batch, _ = synth_batch(32, 256, 10, seed=3)
     b = tuple(t.to(dev) for t in batch)
     x = b[0]
@@ -33,11 +34,11 @@ def test_stress_config_properties(dev):
     g1 = torch.autograd.grad(sr, xr, torch.ones_like(sr), retain_graph=True)[0]
     g3 = torch.autograd.grad(sr, xr, 3 * torch.ones_like(sr))[0]
     assert float((g3 - 3 * g1).abs().max()) <= 1e-5 * float(g1.abs().max())
-    # exact-fp32 and fp32x3 agree on the forward pass at this size
+    # exact-fp32 and the split-operand mode agree on the forward pass at this size
     s.set_precision("fp32")
     with torch.no_grad():
         o32e = s.G(x, b[2])
-    s.set_precision("fp32x3")
+    s.set_precision(mode)
     assert float((o32e - o32).double().norm() / o32e.double().norm()) <= 1e-5
     # two full train steps: finite losses, every weight moved by about lr
     w0 = s.G.main[0].weight.detach().clone()
