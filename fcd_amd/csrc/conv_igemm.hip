@@ -1765,16 +1765,19 @@ __global__ __launch_bounds__(64 * H7_WAVES) void wgrad7_halo_kernel(const WgradA
 // the byte offset is flipped for pixels with bit 3 set, so that the two 4-pixel blocks a read instruction's 32 lanes
 // fetch (8 pixels apart) sit in different halves of the banks at every shift.
 constexpr int W7X_XPLANE = H7_XW * 32;          // bytes per plane of an input ring slot
-constexpr int W7X_XSLOT = 3 * W7X_XPLANE;
 constexpr int W7X_GPLANE = H7_CW * 32;
-constexpr int W7X_GBUF = 3 * W7X_GPLANE;
 __device__ __forceinline__ unsigned w7x_px_off(int px) { return (unsigned)(px * 32) ^ (unsigned)(((px >> 3) & 1) << 7); }
 
+// NP = 2 (FCD_PREC_F16X2 with both maxima): two fp16 planes of the scaled operands, three MFMAs per product group.
+template <int NP>
 __global__ __launch_bounds__(64 * (H7_WAVES + 1)) void wgrad7_halo_x3_kernel(const WgradArgs p, const int rows, const int R,
                                                                              const int nch, const size_t gs_bytes,
                                                                              const size_t xb_bytes) {
-  __shared__ __attribute__((aligned(16))) unsigned char Xp[8 * W7X_XSLOT];
-  __shared__ __attribute__((aligned(16))) unsigned char Gp[2 * W7X_GBUF];
+  constexpr int XSLOT = NP * W7X_XPLANE, GBUF = NP * W7X_GPLANE;
+  __shared__ __attribute__((aligned(16))) unsigned char Xp[8 * XSLOT];
+  __shared__ __attribute__((aligned(16))) unsigned char Gp[2 * GBUF];
+  float sg = 1.f, sx = 1.f;
+  if constexpr (NP == 2) { sg = pow2_scale(p.g_amax); sx = pow2_scale(p.x_amax); }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ch = blockIdx.x % nch, r = blockIdx.x / nch;
@@ -1801,7 +1804,14 @@ __global__ __launch_bounds__(64 * (H7_WAVES + 1)) void wgrad7_halo_x3_kernel(con
     const unsigned voff = ((unsigned)(((y * p.GW + gx) * p.OP + c4 * 4) * 4) & okm) | (OOB & ~okm);
     return __builtin_amdgcn_raw_buffer_load_b128(rgs, (int)voff, 0, 0);
   };
-  auto split_store = [&](const u32x4 v, unsigned char* dst, int plane_bytes) {
+  auto split_store = [&](const u32x4 v, unsigned char* dst, int plane_bytes, float sc) {
+    if constexpr (NP == 2) {
+      uint2 h2, l2;
+      split2_f16(v, sc, h2, l2);
+      *reinterpret_cast<uint2*>(dst) = h2;
+      *reinterpret_cast<uint2*>(dst + plane_bytes) = l2;
+      return;
+    }
     const float f0 = __uint_as_float(v.x), f1 = __uint_as_float(v.y), f2 = __uint_as_float(v.z), f3 = __uint_as_float(v.w);
     const unsigned h0 = cvt_pk_bf16(f0, f1), h1 = cvt_pk_bf16(f2, f3);
     const float r0 = f0 - __uint_as_float(h0 << 16), r1 = f1 - __uint_as_float(h0 & 0xFFFF0000u);
@@ -1814,10 +1824,10 @@ __global__ __launch_bounds__(64 * (H7_WAVES + 1)) void wgrad7_halo_x3_kernel(con
     *reinterpret_cast<uint2*>(dst + 2 * plane_bytes) = make_uint2(cvt_pk_bf16(s0, s1), cvt_pk_bf16(s2, s3));
   };
   auto store_x = [&](const u32x4 v, int f, int yy) {
-    split_store(v, Xp + ((yy + 16) & 7) * W7X_XSLOT + w7x_px_off(f >> 2) + 8 * (f & 3), W7X_XPLANE);
+    split_store(v, Xp + ((yy + 16) & 7) * XSLOT + w7x_px_off(f >> 2) + 8 * (f & 3), W7X_XPLANE, sx);
   };
   auto store_g = [&](const u32x4 v, int f, int y) {
-    split_store(v, Gp + (y & 1) * W7X_GBUF + w7x_px_off(f >> 2) + 8 * (f & 3), W7X_GPLANE);
+    split_store(v, Gp + (y & 1) * GBUF + w7x_px_off(f >> 2) + 8 * (f & 3), W7X_GPLANE, sg);
   };
   // prologue: input rows y0-3 .. y0+3 and gradient row y0, all 512 threads (320 / 256 float4 per row)
   for (int yy = y0 - 3; yy <= y0 + 3; ++yy)
@@ -1863,15 +1873,22 @@ __global__ __launch_bounds__(64 * (H7_WAVES + 1)) void wgrad7_halo_x3_kernel(con
   for (int t = 0; t < 7; ++t) acc[t] = acca[t] = accb[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   __syncthreads();
   for (int y = y0; y < y1; ++y) {
-    const unsigned char* Xrow = Xp + ((y + th - 3 + 16) & 7) * W7X_XSLOT;
-    const unsigned char* Grow = Gp + (y & 1) * W7X_GBUF;
+    const unsigned char* Xrow = Xp + ((y + th - 3 + 16) & 7) * XSLOT;
+    const unsigned char* Grow = Gp + (y & 1) * GBUF;
 #pragma unroll
     for (int ks = 0; ks < H7_CW / 32; ++ks) {
       const int px = 32 * ks + 8 * kq + q;
-      const bf16x8_t gh = frag(Grow, px), gm = frag(Grow + W7X_GPLANE, px), gl = frag(Grow + 2 * W7X_GPLANE, px);
+      const bf16x8_t gh = frag(Grow, px), gm = NP == 3 ? frag(Grow + W7X_GPLANE, px) : gh, gl = frag(Grow + (NP - 1) * W7X_GPLANE, px);
 #pragma unroll
       for (int t = 0; t < 7; ++t) {
-        const bf16x8_t xh = frag(Xrow, px + t), xm = frag(Xrow + W7X_XPLANE, px + t), xl = frag(Xrow + 2 * W7X_XPLANE, px + t);
+        const bf16x8_t xh = frag(Xrow, px + t), xm = NP == 3 ? frag(Xrow + W7X_XPLANE, px + t) : xh,
+                       xl = frag(Xrow + (NP - 1) * W7X_XPLANE, px + t);
+        if constexpr (NP == 2) {
+          acca[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, gl), __builtin_bit_cast(f16x8_t, xh), acca[t], 0, 0, 0);
+          accb[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, gh), __builtin_bit_cast(f16x8_t, xl), accb[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, gh), __builtin_bit_cast(f16x8_t, xh), acc[t], 0, 0, 0);
+          continue;
+        }
         acca[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gl, xh, acca[t], 0, 0, 0);
         accb[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gh, xl, accb[t], 0, 0, 0);
         acca[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gm, xm, acca[t], 0, 0, 0);
@@ -1884,13 +1901,14 @@ __global__ __launch_bounds__(64 * (H7_WAVES + 1)) void wgrad7_halo_x3_kernel(con
   }
   // D[o = 4 kq + e][i = c16] of tap (th, t)
   float* __restrict__ dst = p.slab + (long)((n * R + r) * nch + ch) * p.O * p.ND;
+  const float isc = NP == 2 ? (1.f / sg) * (1.f / sx) : 1.f;      // powers of two: exact
 #pragma unroll
   for (int t = 0; t < 7; ++t) {
     const int col = (th * 7 + t) * p.IP + cg * 16 + c16;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int o = 4 * kq + e;
-      if (o < p.O) dst[(long)o * p.ND + col] = acc[t][e] + (acca[t][e] + accb[t][e]);
+      if (o < p.O) dst[(long)o * p.ND + col] = (acc[t][e] + (acca[t][e] + accb[t][e])) * isc;
     }
   }
 }
@@ -2004,10 +2022,14 @@ __global__ __launch_bounds__(64 * H7_WAVES) void conv7_halo_kernel(const GatherA
 // input row five rows ahead, sums the 7 partial tiles of the previous row in a fixed order (wave 0 .. 6), applies
 // bias / LeakyReLU and stores.  One barrier per output row.
 constexpr int F7X_PLANE = F7_XW * 128;        // bytes per plane of a ring slot (64 bf16 per pixel)
-constexpr int F7X_SLOT = 3 * F7X_PLANE;
+// NP = 2 (FCD_PREC_F16X2 with both maxima): two fp16 planes of the scaled input, weights as two fp16 pieces, three MFMAs.
+template <int NP>
 __global__ __launch_bounds__(64 * (H7_WAVES + 1)) void conv7_halo_x3_kernel(const GatherArgs p, const int rows, const int nch,
                                                                             const size_t in_bytes) {
+  constexpr int F7X_SLOT = NP * F7X_PLANE;
   __shared__ __attribute__((aligned(16))) unsigned char Xp[8 * F7X_SLOT];
+  float a_scale = 1.f, w_scale = 1.f;
+  if constexpr (NP == 2) { a_scale = pow2_scale(p.a_amax); w_scale = pow2_scale(p.w_amax); }
   __shared__ __attribute__((aligned(16))) float Rs[2 * H7_WAVES * F7_CW * 16];   // [row parity][wave][pixel][16 co]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2028,6 +2050,13 @@ __global__ __launch_bounds__(64 * (H7_WAVES + 1)) void conv7_halo_x3_kernel(cons
     const int lpx = f >> 4, c4 = f & 15;
     if (lpx >= F7_CW + 6) return;
     unsigned char* dst = Xp + ((yy + 16) & 7) * F7X_SLOT + lpx * 128 + (((c4 >> 1) ^ (lpx & 7)) << 4) + 8 * (c4 & 1);
+    if constexpr (NP == 2) {
+      uint2 h2, l2;
+      split2_f16(v, a_scale, h2, l2);
+      *reinterpret_cast<uint2*>(dst) = h2;
+      *reinterpret_cast<uint2*>(dst + F7X_PLANE) = l2;
+      return;
+    }
     const float f0 = __uint_as_float(v.x), f1 = __uint_as_float(v.y), f2 = __uint_as_float(v.z), f3 = __uint_as_float(v.w);
     const unsigned h0 = cvt_pk_bf16(f0, f1), h1 = cvt_pk_bf16(f2, f3);
     const float r0 = f0 - __uint_as_float(h0 << 16), r1 = f1 - __uint_as_float(h0 & 0xFFFF0000u);
@@ -2106,8 +2135,10 @@ __global__ __launch_bounds__(64 * (H7_WAVES + 1)) void conv7_halo_x3_kernel(cons
     } else {
       f = f32x8{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     }
-    split3(f, wh[s2], wm[s2], wl[s2]);
+    if constexpr (NP == 2) split2x8(f, w_scale, wh[s2], wl[s2]);
+    else split3(f, wh[s2], wm[s2], wl[s2]);
   }
+  const float isc = NP == 2 ? (1.f / a_scale) * (1.f / w_scale) : 1.f;      // powers of two: exact
   __syncthreads();
 
   for (int y = y0; y < y1; ++y) {
@@ -2122,11 +2153,17 @@ __global__ __launch_bounds__(64 * (H7_WAVES + 1)) void conv7_halo_x3_kernel(cons
       const int P = 16 * mt + c16 + (s2 >> 1);
       const unsigned char* a = Xrow + P * 128 + (((4 * (s2 & 1) + kq) ^ (P & 7)) << 4);
       fh[mt] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(a));
-      fm[mt] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(a + F7X_PLANE));
-      fl[mt] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(a + 2 * F7X_PLANE));
+      if constexpr (NP == 3) fm[mt] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(a + F7X_PLANE));
+      fl[mt] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(a + (NP - 1) * F7X_PLANE));
     };
     // small terms into two side accumulators, the main product into a third: three chains per pixel tile
     auto mfma6 = [&](int s2, int mt) {
+      if constexpr (NP == 2) {
+        acca[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, fl[mt]), __builtin_bit_cast(f16x8_t, wh[s2]), acca[mt], 0, 0, 0);
+        accb[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, fh[mt]), __builtin_bit_cast(f16x8_t, wl[s2]), accb[mt], 0, 0, 0);
+        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, fh[mt]), __builtin_bit_cast(f16x8_t, wh[s2]), acc[mt], 0, 0, 0);
+        return;
+      }
       acca[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fl[mt], wh[s2], acca[mt], 0, 0, 0);
       accb[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[mt], wl[s2], accb[mt], 0, 0, 0);
       acca[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fm[mt], wm[s2], acca[mt], 0, 0, 0);
@@ -2148,7 +2185,7 @@ __global__ __launch_bounds__(64 * (H7_WAVES + 1)) void conv7_halo_x3_kernel(cons
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) R[(16 * mt + 4 * kq + e) * 16 + c16] = acc[mt][e] + (acca[mt][e] + accb[mt][e]);
+      for (int e = 0; e < 4; ++e) R[(16 * mt + 4 * kq + e) * 16 + c16] = (acc[mt][e] + (acca[mt][e] + accb[mt][e])) * isc;
     __syncthreads();
   }
 }
@@ -2168,10 +2205,14 @@ constexpr int C12_CW = 64;            // output columns per workgroup
 constexpr int C12_XW = 72;            // pixels per ring row: 64 + 6 halo, + 2 so that k = 84..95 of the last pixel stays inside
 constexpr int C12_WAVES = 7;          // MFMA waves (one per tap row); an eighth wave loads, splits and sums
 constexpr int C12_ROWB = C12_XW * 12 * 2;                 // bytes per plane row
-constexpr int C12_SLOT = 3 * C12_ROWB;
+// NP = 2 (FCD_PREC_F16X2 with both maxima): two fp16 planes of the scaled input, weights as two fp16 pieces, three MFMAs.
+template <int NP>
 __global__ __launch_bounds__(64 * (C12_WAVES + 1)) void conv7_c12_halo_x3_kernel(const GatherArgs p, const int rows, const int nch,
                                                                                 const size_t in_bytes) {
-  __shared__ __attribute__((aligned(16))) unsigned char Xp[8 * C12_SLOT];
+  constexpr int C12_SLOTN = NP * C12_ROWB;
+  __shared__ __attribute__((aligned(16))) unsigned char Xp[8 * C12_SLOTN];
+  float a_scale = 1.f, w_scale = 1.f;
+  if constexpr (NP == 2) { a_scale = pow2_scale(p.a_amax); w_scale = pow2_scale(p.w_amax); }
   __shared__ __attribute__((aligned(16))) float Rs[2 * C12_WAVES * 32 * 64];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2191,7 +2232,14 @@ __global__ __launch_bounds__(64 * (C12_WAVES + 1)) void conv7_c12_halo_x3_kernel
   auto store_f4 = [&](const u32x4 v, int f, int yy) {
     if (f >= C12_XW * 3) return;
     const int lpx = f / 3, lc4 = f - lpx * 3;
-    unsigned char* dst = Xp + ((yy + 16) & 7) * C12_SLOT + lpx * 24 + lc4 * 8;
+    unsigned char* dst = Xp + ((yy + 16) & 7) * C12_SLOTN + lpx * 24 + lc4 * 8;
+    if constexpr (NP == 2) {
+      uint2 h2, l2;
+      split2_f16(v, a_scale, h2, l2);
+      *reinterpret_cast<uint2*>(dst) = h2;
+      *reinterpret_cast<uint2*>(dst + C12_ROWB) = l2;
+      return;
+    }
     const float f0 = __uint_as_float(v.x), f1 = __uint_as_float(v.y), f2 = __uint_as_float(v.z), f3 = __uint_as_float(v.w);
     const unsigned h0 = cvt_pk_bf16(f0, f1), h1 = cvt_pk_bf16(f2, f3);
     const float r0 = f0 - __uint_as_float(h0 << 16), r1 = f1 - __uint_as_float(h0 & 0xFFFF0000u);
@@ -2276,6 +2324,7 @@ __global__ __launch_bounds__(64 * (C12_WAVES + 1)) void conv7_c12_halo_x3_kernel
   // ================= MFMA waves: tap row th = wave.  Weights: k = tw * 12 + ci (84 real values, zeros up to 96);
   // B fragment of k16-step ks, n-tile ni: lane (co = 32 ni + (lane & 31), k = 16 ks + 8 (lane >> 5) .. +7)
   const int lr = lane & 31, lh = lane >> 5;
+  const float isc = NP == 2 ? (1.f / a_scale) * (1.f / w_scale) : 1.f;      // powers of two: exact
   bf16x8_t wh[6][2], wm[6][2], wl[6][2];
 #pragma unroll
   for (int ks = 0; ks < 6; ++ks)
@@ -2286,14 +2335,15 @@ __global__ __launch_bounds__(64 * (C12_WAVES + 1)) void conv7_c12_halo_x3_kernel
       f32x8 f;
 #pragma unroll
       for (int j = 0; j < 8; ++j) f[j] = (co < p.Cout && k0 + j < 84) ? src[j] : 0.f;
-      split3(f, wh[ks][ni], wm[ks][ni], wl[ks][ni]);
+      if constexpr (NP == 2) split2x8(f, w_scale, wh[ks][ni], wl[ks][ni]);
+      else split3(f, wh[ks][ni], wm[ks][ni], wl[ks][ni]);
     }
   __syncthreads();
 
   for (int y = y0; y < y1; ++y) {
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-      const unsigned char* Arow = Xp + ((y + wave - 3 + 16) & 7) * C12_SLOT + (32 * c + lr) * 24 + 16 * lh;
+      const unsigned char* Arow = Xp + ((y + wave - 3 + 16) & 7) * C12_SLOTN + (32 * c + lr) * 24 + 16 * lh;
       f32x16 acc[2], acc2[2];
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni)
@@ -2303,12 +2353,23 @@ __global__ __launch_bounds__(64 * (C12_WAVES + 1)) void conv7_c12_halo_x3_kernel
       for (int ks = 0; ks < 6; ++ks) {
         bf16x8_t a[3];
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
+        for (int pl = 0; pl < NP; ++pl) {
           const uint2 lo = *reinterpret_cast<const uint2*>(Arow + pl * C12_ROWB + 32 * ks);
           const uint2 hi = *reinterpret_cast<const uint2*>(Arow + pl * C12_ROWB + 32 * ks + 8);
           const u32x4 v = {lo.x, lo.y, hi.x, hi.y};
           a[pl] = __builtin_bit_cast(bf16x8_t, v);
         }
+        if constexpr (NP == 2) {
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+              const f16x8_t av = __builtin_bit_cast(f16x8_t, pc == 0 ? a[1] : a[0]);
+              const f16x8_t bv = __builtin_bit_cast(f16x8_t, pc == 1 ? wl[ks][ni] : wh[ks][ni]);
+              if (pc < 2) acc2[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc2[ni], 0, 0, 0);
+              else acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc[ni], 0, 0, 0);
+            }
+        } else {
 #pragma unroll
         for (int pc = 0; pc < 6; ++pc)
 #pragma unroll
@@ -2318,6 +2379,7 @@ __global__ __launch_bounds__(64 * (C12_WAVES + 1)) void conv7_c12_halo_x3_kernel
             if (pc < 5) acc2[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc2[ni], 0, 0, 0);
             else acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[ni], 0, 0, 0);
           }
+        }
       }
       // D[pixel = (r&3) + 8 (r>>2) + 4 lh][co = 32 ni + lr] -> Rs[parity c][wave][pixel][co].  This parity was last
       // read by the helper for chunk (y-1, c); it reached the barrier of chunk (y-1, c^1) ... (y, c^1) only after that.
@@ -2325,7 +2387,7 @@ __global__ __launch_bounds__(64 * (C12_WAVES + 1)) void conv7_c12_halo_x3_kernel
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) R[((r & 3) + 8 * (r >> 2) + 4 * lh) * 64 + 32 * ni + lr] = acc[ni][r] + acc2[ni][r];
+        for (int r = 0; r < 16; ++r) R[((r & 3) + 8 * (r >> 2) + 4 * lh) * 64 + 32 * ni + lr] = (acc[ni][r] + acc2[ni][r]) * isc;
       __syncthreads();
     }
   }
@@ -2541,12 +2603,16 @@ __global__ __launch_bounds__(64 * W3_WAVES) void wgrad3_halo_x3_kernel(const Wgr
 // the 96 values starting at pixel x" -- overlapping rows of the same memory, read with ds_read_b64_tr_b16 (the
 // MFMA's K axis is the pixel axis).  Wave th = tap row: 32 x 96 accumulators, K = 16 pixels per MFMA.
 constexpr int W12_GPLANE = C12_CW * 64;          // bytes per plane of a gradient buffer ([pixel][32 channels] bf16)
-constexpr int W12_GBUF = 3 * W12_GPLANE;
+// NP = 2 (FCD_PREC_F16X2 with both maxima): two fp16 planes of the scaled operands, three MFMAs per product group.
+template <int NP>
 __global__ __launch_bounds__(64 * (C12_WAVES + 1)) void wgrad7_c12_halo_x3_kernel(const WgradArgs p, const int rows, const int R,
                                                                                  const int nch, const int halves,
                                                                                  const size_t gs_bytes, const size_t xb_bytes) {
-  __shared__ __attribute__((aligned(16))) unsigned char Xp[8 * C12_SLOT];       // (columns 84 .. 95 of the last pixels stay inside the 72-pixel row)
-  __shared__ __attribute__((aligned(16))) unsigned char Gp[2 * W12_GBUF];
+  constexpr int XSLOT = NP * C12_ROWB, GBUF = NP * W12_GPLANE;
+  __shared__ __attribute__((aligned(16))) unsigned char Xp[8 * XSLOT];          // (columns 84 .. 95 of the last pixels stay inside the 72-pixel row)
+  __shared__ __attribute__((aligned(16))) unsigned char Gp[2 * GBUF];
+  float sg = 1.f, sx = 1.f;
+  if constexpr (NP == 2) { sg = pow2_scale(p.g_amax); sx = pow2_scale(p.x_amax); }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ch = blockIdx.x % nch, r = blockIdx.x / nch;
@@ -2572,7 +2638,14 @@ __global__ __launch_bounds__(64 * (C12_WAVES + 1)) void wgrad7_c12_halo_x3_kerne
     const unsigned voff = ((unsigned)(((y * p.GW + gx) * p.OP + c) * 4) & okm) | (OOB & ~okm);
     return __builtin_amdgcn_raw_buffer_load_b128(rgs, (int)voff, 0, 0);
   };
-  auto split_store = [&](const u32x4 v, unsigned char* dst, int plane_bytes) {
+  auto split_store = [&](const u32x4 v, unsigned char* dst, int plane_bytes, float sc) {
+    if constexpr (NP == 2) {
+      uint2 h2, l2;
+      split2_f16(v, sc, h2, l2);
+      *reinterpret_cast<uint2*>(dst) = h2;
+      *reinterpret_cast<uint2*>(dst + plane_bytes) = l2;
+      return;
+    }
     const float f0 = __uint_as_float(v.x), f1 = __uint_as_float(v.y), f2 = __uint_as_float(v.z), f3 = __uint_as_float(v.w);
     const unsigned h0 = cvt_pk_bf16(f0, f1), h1 = cvt_pk_bf16(f2, f3);
     const float r0 = f0 - __uint_as_float(h0 << 16), r1 = f1 - __uint_as_float(h0 & 0xFFFF0000u);
@@ -2585,9 +2658,9 @@ __global__ __launch_bounds__(64 * (C12_WAVES + 1)) void wgrad7_c12_halo_x3_kerne
     *reinterpret_cast<uint2*>(dst + 2 * plane_bytes) = make_uint2(cvt_pk_bf16(s0, s1), cvt_pk_bf16(s2, s3));
   };
   auto store_x = [&](const u32x4 v, int f, int yy) {
-    if (f < C12_XW * 3) split_store(v, Xp + ((yy + 16) & 7) * C12_SLOT + f * 8, C12_ROWB);
+    if (f < C12_XW * 3) split_store(v, Xp + ((yy + 16) & 7) * XSLOT + f * 8, C12_ROWB, sx);
   };
-  auto store_g = [&](const u32x4 v, int f, int y) { split_store(v, Gp + (y & 1) * W12_GBUF + f * 8, W12_GPLANE); };
+  auto store_g = [&](const u32x4 v, int f, int y) { split_store(v, Gp + (y & 1) * GBUF + f * 8, W12_GPLANE, sg); };
   // prologue: input rows y0-3 .. y0+3 and gradient row y0, all 512 threads (216 / 512 float4 per row)
   for (int yy = y0 - 3; yy <= y0 + 3; ++yy) store_x(load_x(tid, yy), tid, yy);
   store_g(load_g(tid, y0), tid, y0);
@@ -2634,22 +2707,34 @@ __global__ __launch_bounds__(64 * (C12_WAVES + 1)) void wgrad7_c12_halo_x3_kerne
     for (int e = 0; e < 16; ++e) acc[t][e] = acc2[t][e] = 0.f;
   __syncthreads();
   for (int y = y0; y < y1; ++y) {
-    const unsigned char* Xrow = Xp + ((y + th - 3 + 16) & 7) * C12_SLOT;
-    const unsigned char* Grow = Gp + (y & 1) * W12_GBUF;
+    const unsigned char* Xrow = Xp + ((y + th - 3 + 16) & 7) * XSLOT;
+    const unsigned char* Grow = Gp + (y & 1) * GBUF;
 #pragma unroll
     for (int ks = 0; ks < C12_CW / 16; ++ks) {
       const unsigned ao = a_off + ks * 16 * 64, bo = b_off + ks * 16 * 24;
-      const bf16x8_t gh = frag(Grow, ao, ao + 4 * 64), gm = frag(Grow + W12_GPLANE, ao, ao + 4 * 64),
-                     gl = frag(Grow + 2 * W12_GPLANE, ao, ao + 4 * 64);
+      const bf16x8_t gh = frag(Grow, ao, ao + 4 * 64), gm = NP == 3 ? frag(Grow + W12_GPLANE, ao, ao + 4 * 64) : gh,
+                     gl = frag(Grow + (NP - 1) * W12_GPLANE, ao, ao + 4 * 64);
       bf16x8_t xh[3], xm[3], xl[3];
 #pragma unroll
       for (int t = 0; t < 3; ++t) {
         const unsigned bt = bo + t * 64;
         xh[t] = frag(Xrow, bt, bt + 4 * 24);
-        xm[t] = frag(Xrow + C12_ROWB, bt, bt + 4 * 24);
-        xl[t] = frag(Xrow + 2 * C12_ROWB, bt, bt + 4 * 24);
+        if constexpr (NP == 3) xm[t] = frag(Xrow + C12_ROWB, bt, bt + 4 * 24);
+        xl[t] = frag(Xrow + (NP - 1) * C12_ROWB, bt, bt + 4 * 24);
       }
       // piece pairs outermost (small terms first): consecutive MFMAs go to different accumulators
+      if constexpr (NP == 2) {
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+          for (int t = 0; t < 3; ++t) {
+            const f16x8_t a = __builtin_bit_cast(f16x8_t, pc == 0 ? gl : gh);
+            const f16x8_t b = __builtin_bit_cast(f16x8_t, pc == 1 ? xl[t] : xh[t]);
+            if (pc < 2) acc2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc2[t], 0, 0, 0);
+            else acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[t], 0, 0, 0);
+          }
+        continue;
+      }
 #pragma unroll
       for (int pc = 0; pc < 6; ++pc)
 #pragma unroll
@@ -2665,6 +2750,7 @@ __global__ __launch_bounds__(64 * (C12_WAVES + 1)) void wgrad7_c12_halo_x3_kerne
   // D[o = 32 half + (e & 3) + 8 (e >> 2) + 4 (lane >> 5)][column j = 32 t + (lane & 31)] of tap row th; j = tw * 12 + ci < 84
   float* __restrict__ dst = p.slab + (long)((n * R + r) * nch + ch) * p.O * p.ND;
   const int lr = lane & 31, lh = lane >> 5;
+  const float isc = NP == 2 ? (1.f / sg) * (1.f / sx) : 1.f;      // powers of two: exact
 #pragma unroll
   for (int t = 0; t < 3; ++t) {
     const int j = 32 * t + lr;
@@ -2672,7 +2758,7 @@ __global__ __launch_bounds__(64 * (C12_WAVES + 1)) void wgrad7_c12_halo_x3_kerne
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int o = 32 * half + (e & 3) + 8 * (e >> 2) + 4 * lh;
-      if (o < p.O) dst[(long)o * p.ND + th * 84 + j] = acc[t][e] + acc2[t][e];
+      if (o < p.O) dst[(long)o * p.ND + th * 84 + j] = (acc[t][e] + acc2[t][e]) * isc;
     }
   }
 }
@@ -3039,17 +3125,29 @@ int run_gather(const FcdConvDesc* d, GatherArgs& a, hipStream_t st) {
   gather_tile(d, bm, bn);
   if (const int rows = (a.bias || a.mask || a.res) ? 0 : halo12_rows(d, nullptr)) {
     const int nch = fcd_cdiv(d->GW, C12_CW), R = fcd_cdiv(d->GH, rows);
-    note_kernel("conv7_c12_halo_x3_kernel");
-    hipLaunchKernelGGL(conv7_c12_halo_x3_kernel, dim3(nch * R, d->N), dim3(64 * (C12_WAVES + 1)), 0, st, a, rows, nch,
-                       (size_t)a.N * a.IH * a.IW * a.Cin * 4);
+    if (a.a_amax && a.w_amax) {
+      note_kernel("conv7_c12_halo_x3_kernel<2>");
+      hipLaunchKernelGGL(conv7_c12_halo_x3_kernel<2>, dim3(nch * R, d->N), dim3(64 * (C12_WAVES + 1)), 0, st, a, rows, nch,
+                         (size_t)a.N * a.IH * a.IW * a.Cin * 4);
+    } else {
+      note_kernel("conv7_c12_halo_x3_kernel");
+      hipLaunchKernelGGL(conv7_c12_halo_x3_kernel<3>, dim3(nch * R, d->N), dim3(64 * (C12_WAVES + 1)), 0, st, a, rows, nch,
+                         (size_t)a.N * a.IH * a.IW * a.Cin * 4);
+    }
     return fcd_check_launch("conv7_c12_halo_x3");
   }
   if (const int rows = halo7_fwd_rows(d, a)) {
     const int nch = fcd_cdiv(d->GW, F7_CW), R = fcd_cdiv(d->GH, rows);
     if (d->precision == FCD_PREC_BF16X3 && d->CoutP % 4 == 0 && !getenv("FCD_NO_HALO7X")) {
-      note_kernel("conv7_halo_x3_kernel");
-      hipLaunchKernelGGL(conv7_halo_x3_kernel, dim3(nch * R, d->N), dim3(64 * (H7_WAVES + 1)), 0, st, a, rows, nch,
-                         (size_t)a.N * a.IH * a.IW * a.Cin * 4);
+      if (a.a_amax && a.w_amax) {
+        note_kernel("conv7_halo_x3_kernel<2>");
+        hipLaunchKernelGGL(conv7_halo_x3_kernel<2>, dim3(nch * R, d->N), dim3(64 * (H7_WAVES + 1)), 0, st, a, rows, nch,
+                           (size_t)a.N * a.IH * a.IW * a.Cin * 4);
+      } else {
+        note_kernel("conv7_halo_x3_kernel");
+        hipLaunchKernelGGL(conv7_halo_x3_kernel<3>, dim3(nch * R, d->N), dim3(64 * (H7_WAVES + 1)), 0, st, a, rows, nch,
+                           (size_t)a.N * a.IH * a.IW * a.Cin * 4);
+      }
       return fcd_check_launch("conv7_halo_x3");
     }
     note_kernel("conv7_halo_kernel");
@@ -3146,18 +3244,23 @@ int fused_stats_chunks(const FcdConvDesc* d) {
 // BF16X3) plus this flag.
 struct NormDesc {
   FcdConvDesc d;
-  bool h2;
+  bool h2;       // two fp16 weight planes (format 2): both maxima required
+  bool h2opt;    // fp32 weights split inside the kernel (the 7x7 halo kernels, format 3): two-piece form if both maxima are given
 };
 NormDesc normalise(const FcdConvDesc* d) {
   NormDesc n;
   n.d = *d;
-  n.h2 = false;
+  n.h2 = n.h2opt = false;
   if (d->precision == FCD_PREC_F16X2) {
     n.d.precision = FCD_PREC_BF16X3;
-    if (validate_conv(&n.d) == FCD_OK && wants_split_weights(&n.d)) {
-      int bm, bn;
-      gather_tile(&n.d, bm, bn);
-      n.h2 = true;       // every pre-split (format 1) shape has a two-plane form
+    if (validate_conv(&n.d) == FCD_OK) {
+      if (wants_split_weights(&n.d)) {
+        n.h2 = true;       // every pre-split (format 1) shape has a two-plane form
+      } else {
+        GatherArgs plain{};
+        plain.splitk = 1;
+        n.h2opt = halo12_rows(&n.d, nullptr) > 0 || (halo7_fwd_rows(&n.d, plain) > 0 && n.d.CoutP % 4 == 0);
+      }
     }
   }
   return n;
@@ -3169,6 +3272,7 @@ extern "C" int fcd_conv_weight_format(const FcdConvDesc* d) {
   if (!d) return 0;
   const NormDesc n = normalise(d);
   if (n.h2) return 2;
+  if (n.h2opt) return 3;
   return (validate_conv(&n.d) == FCD_OK && wants_split_weights(&n.d)) ? 1 : 0;
 }
 
@@ -3177,8 +3281,9 @@ extern "C" int fcd_conv_gather(const FcdConvDesc* d, const float* in, const floa
                                float* out, void* workspace, size_t workspace_bytes, void* stream) {
   FCD_REQUIRE(d != nullptr, "conv: null descriptor");
   const NormDesc nd = normalise(d);
-  const float* a_amax = nd.h2 ? d->a_amax : nullptr;
-  const float* w_amax = nd.h2 ? d->w_amax : nullptr;
+  const bool both = d->a_amax && d->w_amax;
+  const float* a_amax = (nd.h2 || (nd.h2opt && both)) ? d->a_amax : nullptr;
+  const float* w_amax = (nd.h2 || (nd.h2opt && both)) ? d->w_amax : nullptr;
   FCD_REQUIRE(!nd.h2 || (a_amax && w_amax), "conv: FCD_PREC_F16X2 needs a_amax and w_amax");
   d = &nd.d;
   int rc = validate_conv(d);
@@ -3216,8 +3321,9 @@ extern "C" int fcd_conv_gather_stats(const FcdConvDesc* d, const float* in, cons
   FCD_REQUIRE(d != nullptr, "conv_stats: null descriptor");
   const FcdConvDesc* d_orig = d;
   const NormDesc nd = normalise(d);
-  const float* a_amax = nd.h2 ? d->a_amax : nullptr;
-  const float* w_amax = nd.h2 ? d->w_amax : nullptr;
+  const bool both = d->a_amax && d->w_amax;
+  const float* a_amax = (nd.h2 || (nd.h2opt && both)) ? d->a_amax : nullptr;
+  const float* w_amax = (nd.h2 || (nd.h2opt && both)) ? d->w_amax : nullptr;
   FCD_REQUIRE(!nd.h2 || (a_amax && w_amax), "conv_stats: FCD_PREC_F16X2 needs a_amax and w_amax");
   d = &nd.d;
   int rc = validate_conv(d);
@@ -3401,9 +3507,16 @@ extern "C" int fcd_conv_wgrad(const FcdWgradDesc* d, const float* gsmall, const 
     a.splitk = halo;
     dim3 grid(h_nch * h_R, d->N * (d->IP / 16));
     if (d->precision == FCD_PREC_BF16X3 && !getenv("FCD_NO_WGRAD7X")) {
-      note_kernel("wgrad7_halo_x3_kernel");
-      hipLaunchKernelGGL(wgrad7_halo_x3_kernel, grid, dim3(64 * (H7_WAVES + 1)), 0, st, a, h_rows, h_R, h_nch,
-                         (size_t)a.P * a.OP * 4, (size_t)a.N * a.BH * a.BW * a.IP * 4);
+      if (want_h2) {
+        a.g_amax = g_amax; a.x_amax = x_amax;
+        note_kernel("wgrad7_halo_x3_kernel<2>");
+        hipLaunchKernelGGL(wgrad7_halo_x3_kernel<2>, grid, dim3(64 * (H7_WAVES + 1)), 0, st, a, h_rows, h_R, h_nch,
+                           (size_t)a.P * a.OP * 4, (size_t)a.N * a.BH * a.BW * a.IP * 4);
+      } else {
+        note_kernel("wgrad7_halo_x3_kernel");
+        hipLaunchKernelGGL(wgrad7_halo_x3_kernel<3>, grid, dim3(64 * (H7_WAVES + 1)), 0, st, a, h_rows, h_R, h_nch,
+                           (size_t)a.P * a.OP * 4, (size_t)a.N * a.BH * a.BW * a.IP * 4);
+      }
     } else {
       note_kernel("wgrad7_halo_kernel");
       hipLaunchKernelGGL(wgrad7_halo_kernel, grid, dim3(64 * H7_WAVES), 0, st, a, h_rows, h_R, h_nch,
@@ -3428,9 +3541,16 @@ extern "C" int fcd_conv_wgrad(const FcdWgradDesc* d, const float* gsmall, const 
   } else if (int hv = 0, slabs12 = halo12w_plan(d, &h_rows, &h_R, &h_nch, &hv); slabs12) {
     a.splitk = slabs12;
     dim3 grid(h_nch * h_R, d->N * hv);
-    note_kernel("wgrad7_c12_halo_x3_kernel");
-    hipLaunchKernelGGL(wgrad7_c12_halo_x3_kernel, grid, dim3(64 * (C12_WAVES + 1)), 0, st, a, h_rows, h_R, h_nch, hv,
-                       (size_t)a.P * a.OP * 4, (size_t)a.N * a.BH * a.BW * a.IP * 4);
+    if (want_h2) {
+      a.g_amax = g_amax; a.x_amax = x_amax;
+      note_kernel("wgrad7_c12_halo_x3_kernel<2>");
+      hipLaunchKernelGGL(wgrad7_c12_halo_x3_kernel<2>, grid, dim3(64 * (C12_WAVES + 1)), 0, st, a, h_rows, h_R, h_nch, hv,
+                         (size_t)a.P * a.OP * 4, (size_t)a.N * a.BH * a.BW * a.IP * 4);
+    } else {
+      note_kernel("wgrad7_c12_halo_x3_kernel");
+      hipLaunchKernelGGL(wgrad7_c12_halo_x3_kernel<3>, grid, dim3(64 * (C12_WAVES + 1)), 0, st, a, h_rows, h_R, h_nch, hv,
+                         (size_t)a.P * a.OP * 4, (size_t)a.N * a.BH * a.BW * a.IP * 4);
+    }
     rc = fcd_check_launch("conv_wgrad");
   } else if (d->O <= 16 && d->precision != FCD_PREC_BF16) {   // exact fp32 16-row kernel, also under BF16X3
     a.tiles_m = 1; a.tiles_n = fcd_cdiv(a.ND, 128);

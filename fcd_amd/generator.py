@@ -62,36 +62,48 @@ class ConvParams(nn.Module):
 
     def operand(self, kind: str, geom: ConvGeom, d) -> torch.Tensor:
         """The packed weights convolution ``d`` wants: fp32, three bf16 planes (BF16X3, 128x128 tiles), or two fp16
-        planes of the scaled weights (PREC_F16X2 on the A-halo layers; also sets ``d.w_amax``)."""
+        planes of the scaled weights (PREC_F16X2; also sets ``d.w_amax``, as for the 7x7 halo kernels that split
+        fp32 weights themselves)."""
         fmt = ops.weight_format(d)
         if fmt == 2:
             t, wa = self.packed(kind + "h", geom)
             d.w_amax = wa.data_ptr()
             return t
+        if fmt == 3:
+            d.w_amax = self.weight_amax().data_ptr()
         return self.packed(kind + "3" if fmt == 1 else kind, geom)
+
+    def _key(self):
+        w = self.weight
+        return (w.data_ptr(), w._version, str(w.device))
+
+    def weight_amax(self) -> torch.Tensor:
+        """max |weight| (AMAX_SLOTS partial maxima on the device), once per parameter version."""
+        key = self._key()
+        hit = self._packed.get("amax")
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                hit = (key, ops.absmax(self.weight.detach().contiguous()))
+            self._packed["amax"] = hit
+        return hit[1]
 
     def packed(self, kind: str, geom: ConvGeom) -> torch.Tensor:
         """Operand layout for the gather kernel, rebuilt when the parameter changed."""
         w = self.weight
-        key = (w.data_ptr(), w._version, str(w.device))
+        key = self._key()
         hit = self._packed.get(kind)
         if hit is not None and hit[0] == key:
             return hit[1]
         with torch.no_grad():
             wd = w.detach().contiguous()
             if kind.endswith("h"):
-                hit_a = self._packed.get("amax")
-                if hit_a is None or hit_a[0] != key:
-                    hit_a = (key, ops.absmax(wd))
-                    self._packed["amax"] = hit_a
-                wa = hit_a[1]
+                wa = self.weight_amax()
                 t = ((ops.pack_weight_fwd_h2 if kind == "fwdh" else ops.pack_weight_adj_h2)(wd, geom, wa), wa)
             else:
                 t = {"fwd": ops.pack_weight_fwd, "adj": ops.pack_weight_adj, "fwd3": ops.pack_weight_fwd_x3,
                      "adj3": ops.pack_weight_adj_x3}[kind](wd, geom)
         self._packed[kind] = (key, t)
         return t
-
 
     def folded(self, geom: ConvGeom, d, norm, epoch: int = 0) -> tuple:
         """Inference only: the forward operand with a tracked InstanceNorm's eval-mode transform folded
@@ -407,9 +419,8 @@ class _GeneratorFn(torch.autograd.Function):
                     ops.absmax(dz, out=gmx[li])
                     dz_ok = True
                 return gmx[li]
-            # weight gradient (PREC_F16X2: the kernels with a two-plane form want max |.| of both operands; the 7x7
-            # image layers' kernels run as BF16X3 and ignore them)
-            h2_w = h2 and prec_w == L.PREC_F16X2 and gm.k != 7
+            # weight gradient (PREC_F16X2: the kernels with a two-plane form want max |.| of both operands)
+            h2_w = h2 and prec_w == L.PREC_F16X2
             if needs[p0]:
                 sink = grad_sink(ly.conv.weight, True)     # arena-backed: accumulate into p.grad in place
                 if ly.kind == "conv":

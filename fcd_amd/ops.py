@@ -124,7 +124,8 @@ class ConvGeom:
 
 
 def weight_format(d: ConvDesc) -> int:
-    """0 = fp32 pack, 1 = three bf16 planes, 2 = two fp16 planes of the scaled weights (PREC_F16X2 on A-halo layers)."""
+    """0 = fp32 pack, 1 = three bf16 planes, 2 = two fp16 planes of the scaled weights (PREC_F16X2), 3 = fp32 pack and
+    the kernel takes the two-fp16-piece form if both maxima are set (PREC_F16X2 on the 7x7 halo kernels)."""
     return int(L.load().fcd_conv_weight_format(C.byref(d)))
 
 

@@ -680,3 +680,53 @@ def test_gather_per_tap_f16x2(dev, geom):
         ref = F.conv_transpose2d(gy.double(), wt.double(), None, 2, 1) * torch.where(mask > 0, 1.0, 0.2) + res
         assert relerr(from_nhwc(got.cpu(), I).double(), ref) <= 1e-6
     assert L.load().fcd_last_conv_kernel().endswith(b"false, 2>")
+
+
+@pytest.mark.parametrize("case", [(64, 11, 2, 40, 72, "fwd", 30.0), (10, 64, 2, 33, 64, "adj", 1e-4), (10, 64, 3, 24, 70, "fwd", 1.0),
+                                  (16, 64, 1, 16, 32, "fwd", 1.0)])
+def test_conv7_halo_f16x2(dev, case):
+    """The 7x7 image-layer kernels under FCD_PREC_F16X2 (weight format 3: fp32 packs, operands scaled and split into
+    two fp16 pieces inside the kernel when both maxima are attached): <= 1e-6 of max |result| from torch in float64; the
+    same descriptor without maxima runs the BF16X3 form."""
+    from fcd_amd import _lib as L, ops
+    O, I, n, h, w, form, sc = case
+    g = ops.ConvGeom(O, I, 7, 1, 3)
+    gen = torch.Generator().manual_seed(41)
+    wt = torch.randn(O, I, 7, 7, generator=gen) / (7 * I ** 0.5)
+    cin, cout = (I, O) if form == "fwd" else (O, I)
+    x = torch.randn(n, cin, h, w, generator=gen) * sc
+    xd = to_nhwc(x, g.IP if form == "fwd" else g.OP).to(dev)
+    wd = wt.to(dev)
+    def mk():
+        d_ = g.fwd_desc(n, h, w, precision=L.PREC_F16X2) if form == "fwd" else g.adj_desc(n, h, w, precision=L.PREC_F16X2)
+        d_.splitk = 1          # (small test shapes would otherwise take split-K and the generic kernel)
+        return d_
+    d = mk()
+    assert ops.weight_format(d) == 3
+    wp = ops.pack_weight_fwd(wd, g) if form == "fwd" else ops.pack_weight_adj(wd, g)
+    ops.set_amax(d, ops.absmax(xd), ops.absmax(wd))
+    got = ops.conv_gather(d, xd, wp)
+    assert L.load().fcd_last_conv_kernel().endswith(b"halo_x3_kernel<2>")
+    ref = F.conv2d(x.double(), wt.double(), None, 1, 3) if form == "fwd" else F.conv_transpose2d(x.double(), wt.double(), None, 1, 3)
+    assert relerr(from_nhwc(got.cpu(), cout).double(), ref) <= 1e-6
+    plain = ops.conv_gather(mk(), xd, wp)
+    assert L.load().fcd_last_conv_kernel().endswith(b"halo_x3_kernel")
+    assert relerr(from_nhwc(plain.cpu(), cout).double(), ref) <= 1e-6
+
+
+@pytest.mark.parametrize("case", [(10, 64, 2, 40, 72, 1e-3, 1.0), (64, 11, 3, 33, 70, 1.0, 25.0), (16, 16, 1, 70, 64, 1.0, 1.0)])
+def test_wgrad7_halo_f16x2(dev, case):
+    """Weight gradients of the 7x7 image layers under FCD_PREC_F16X2 with both maxima attached (two fp16 planes of the
+    scaled gradient and input rows): <= 1e-6 of max |dW| from torch in float64."""
+    from fcd_amd import _lib as L, ops
+    O, I, n, h, w, sg, sx = case
+    g = ops.ConvGeom(O, I, 7, 1, 3)
+    gen = torch.Generator().manual_seed(43)
+    x = torch.randn(n, I, h, w, generator=gen) * sx
+    gy = torch.randn(n, O, h, w, generator=gen) * sg
+    xd, gd = to_nhwc(x, g.IP).to(dev), to_nhwc(gy, g.OP).to(dev)
+    d = ops.set_wgrad_amax(g.wgrad_desc(n, h, w, precision=L.PREC_F16X2), ops.absmax(gd), ops.absmax(xd))
+    dw = ops.conv_wgrad(d, gd, xd)
+    assert L.load().fcd_last_conv_kernel().endswith(b"halo_x3_kernel<2>")
+    ref = torch.nn.grad.conv2d_weight(x.double(), (O, I, 7, 7), gy.double(), stride=1, padding=3)
+    assert relerr(dw.cpu(), ref) <= 1e-6
