@@ -39,6 +39,7 @@ class ConvDesc(C.Structure):
         ("splitk", C.c_int32), ("precision", C.c_int32),
         ("act_slope", C.c_float), ("mask_slope", C.c_float),
         ("a_amax", C.c_void_p), ("w_amax", C.c_void_p),          # FCD_PREC_F16X2 only
+        ("out_amax", C.c_void_p),                                # optional: max |out| of the launch (AMAX_SLOTS floats)
     ]
 
 

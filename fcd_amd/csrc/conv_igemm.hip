@@ -39,6 +39,8 @@ struct GatherArgs {
   int stats_cpp;   // wave row-chunks per phase per image = GH*GW / WTM
   const float* a_amax;   // FCD_PREC_F16X2: max |activation operand| and max |weight| (device scalars): the operands are
   const float* w_amax;   // scaled by powers of two derived from them before the fp16 split
+  unsigned* out_amax;    // optional: max |out| of this launch into FCD_AMAX_SLOTS per-block slots (pre-split kernels, no split-K)
+  int out_amax_in_kernel; // host side: the launched kernel records out_amax itself (else the entry point runs fcd_absmax)
 };
 
 __device__ __forceinline__ float epilogue_value(float v, int co, long o, const GatherArgs& p) {
@@ -1000,6 +1002,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
   // finalize_kernel<FIN_STATS>; saves the separate read of the output tensor
   // (sums of v - ssh and (v - ssh)^2, ssh = the lane's first value of the column: keeps the variance of a
   // channel with |mean| >> std out of the fp32 rounding of sum v^2; undone in double below)
+  float omax = 0.f;          // max |stored value| of this thread (out_amax)
   float ssum[TN], qsum[TN], ssh[TN];
   int scnt[TN];
 #pragma unroll
@@ -1045,7 +1048,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        if (off[r] >= 0) dst[off[r] + co] = v[r];
+        if (off[r] >= 0) {
+          dst[off[r] + co] = v[r];
+          omax = fmaxf(omax, fabsf(v[r]));
+        }
       if (p.stats) {
 #pragma unroll
         for (int r = 0; r < 16; ++r)
@@ -1076,6 +1082,27 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
           d2[0] = s2;
           d2[1] = q2;
         }
+      }
+    }
+  }
+  if (p.out_amax) {
+    // max |out| of the workgroup into its slot (one plain read-max-write when the grid has at most FCD_AMAX_SLOTS
+    // workgroups; see norm.hip: block_absmax).  Only launched with splitk == 1, so every value stored above is final.
+    __shared__ float wave_max[NW];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) omax = fmaxf(omax, __shfl_xor(omax, o));
+    if (lane == 0) wave_max[wave] = omax;
+    __syncthreads();
+    if (tid == 0) {
+      float m = 0.f;
+#pragma unroll
+      for (int i = 0; i < NW; ++i) m = fmaxf(m, wave_max[i]);
+      const unsigned b = __float_as_uint(m), blocks = gridDim.x * gridDim.y;
+      unsigned* slot = p.out_amax + ((blockIdx.y * gridDim.x + blockIdx.x) & (FCD_AMAX_SLOTS - 1));
+      if (blocks <= FCD_AMAX_SLOTS) {
+        if (b > *slot) *slot = b;
+      } else if (b > __builtin_nontemporal_load(slot)) {
+        atomicMax(slot, b);
       }
     }
   }
@@ -3021,7 +3048,8 @@ void fill_gather_args(const FcdConvDesc* d, GatherArgs& a) {
   a.stats = nullptr;
   a.stats_cpp = 0;
   a.a_amax = a.w_amax = nullptr;
-
+  a.out_amax = nullptr;
+  a.out_amax_in_kernel = 0;
 }
 
 }  // namespace
@@ -3123,6 +3151,11 @@ int halo12_rows(const FcdConvDesc* d, int* nchunks) {
 int run_gather(const FcdConvDesc* d, GatherArgs& a, hipStream_t st) {
   int bm, bn, rc;
   gather_tile(d, bm, bn);
+  // max |out|: recorded by the epilogue of the 32-wide-tile gather kernels when they write final values (no split-K);
+  // the halo kernels, the 16-wide variant and split-K launches leave it to the entry point (an fcd_absmax pass)
+  unsigned* const want_amax = a.out_amax;
+  a.out_amax = nullptr;
+  a.out_amax_in_kernel = 0;
   if (const int rows = (a.bias || a.mask || a.res) ? 0 : halo12_rows(d, nullptr)) {
     const int nch = fcd_cdiv(d->GW, C12_CW), R = fcd_cdiv(d->GH, rows);
     if (a.a_amax && a.w_amax) {
@@ -3159,6 +3192,7 @@ int run_gather(const FcdConvDesc* d, GatherArgs& a, hipStream_t st) {
     a.tiles_m = fcd_cdiv(a.M, 128);
     a.tiles_n = fcd_cdiv(d->Cout, bn);
     const bool h2 = a.a_amax != nullptr;                 // FCD_PREC_F16X2: two fp16 planes instead of three bf16 ones
+    if (want_amax && a.splitk == 1) { a.out_amax = want_amax; a.out_amax_in_kernel = 1; }
     a.w_phase_stride = h2 ? (long)d->Cout * a.K : (long)d->Cout * a.K * 3 / 2;      // in units of 4 bytes
     dim3 grid(a.tiles_m * a.tiles_n, a.nphase * a.splitk);
     const size_t in_bytes = (size_t)a.N * a.IH * a.IW * a.Cin * 4;
@@ -3208,12 +3242,15 @@ int run_gather(const FcdConvDesc* d, GatherArgs& a, hipStream_t st) {
     hipLaunchKernelGGL((conv_gather_dma_kernel<128, 32, 4, 1, 3, FCD_PREC_F32, true>), grid, dim3(256), 0, st, a,
                        (size_t)a.N * a.IH * a.IW * a.Cin * 4, (unsigned)((size_t)a.Cout * a.K * 4));
     rc = fcd_check_launch("conv_gather");
-  } else if (bm == 128 && bn == 32) rc = launch_gather<128, 32, 4, 1>(a, d->precision, st);
-  else if (bm == 128 && bn == 64) rc = launch_gather<128, 64, 4, 2>(a, d->precision, st);
-  else if (bm == 64 && bn == 128) rc = launch_gather<64, 128, 2, 4>(a, d->precision, st);
-  else if (bm == 64 && bn == 64) rc = launch_gather<64, 64, 2, 2>(a, d->precision, st);
-  else if (bm == 128 && bn == 128) rc = launch_gather<128, 128, 2, 4>(a, d->precision, st);
-  else { fcd_set_error("conv: no %dx%d tile", bm, bn); return FCD_EINVAL; }
+  } else {
+    if (want_amax && a.splitk == 1) { a.out_amax = want_amax; a.out_amax_in_kernel = 1; }
+    if (bm == 128 && bn == 32) rc = launch_gather<128, 32, 4, 1>(a, d->precision, st);
+    else if (bm == 128 && bn == 64) rc = launch_gather<128, 64, 4, 2>(a, d->precision, st);
+    else if (bm == 64 && bn == 128) rc = launch_gather<64, 128, 2, 4>(a, d->precision, st);
+    else if (bm == 64 && bn == 64) rc = launch_gather<64, 64, 2, 2>(a, d->precision, st);
+    else if (bm == 128 && bn == 128) rc = launch_gather<128, 128, 2, 4>(a, d->precision, st);
+    else { fcd_set_error("conv: no %dx%d tile", bm, bn); return FCD_EINVAL; }
+  }
   if (rc) return rc;
   if (a.splitk > 1) {
     const long total = (long)a.nphase * a.M * a.CoutP;
@@ -3300,7 +3337,11 @@ extern "C" int fcd_conv_gather(const FcdConvDesc* d, const float* in, const floa
   a.in = in; a.w = w_packed; a.bias = bias; a.mask = mask_src; a.res = residual; a.out = out;
   a.slab = (float*)workspace;
   a.a_amax = a_amax; a.w_amax = w_amax;
-  return run_gather(d, a, fcd_stream(stream));
+  a.out_amax = reinterpret_cast<unsigned*>(d->out_amax);
+  rc = run_gather(d, a, fcd_stream(stream));
+  if (rc == FCD_OK && d->out_amax && !a.out_amax_in_kernel)
+    rc = fcd_absmax(out, (size_t)d->N * d->OH * d->OW * d->CoutP, d->out_amax, stream);
+  return rc;
 }
 
 extern "C" size_t fcd_conv_gather_stats_workspace_bytes(const FcdConvDesc* d) {

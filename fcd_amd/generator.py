@@ -114,17 +114,24 @@ class ConvParams(nn.Module):
         kernel-side running-statistics updates, which bypass tensor versions), ``t`` goes in as the bias, the activation
         and the residual add ride in the convolution's epilogue, and no norm kernel runs at all."""
         srcs = (self.weight, norm.weight, norm.bias, norm.running_mean, norm.running_var)
-        x3 = ops.wants_split_weights(d)
-        key = tuple((t.data_ptr(), t._version) for t in srcs) + (x3, str(self.weight.device), epoch)
+        fmt = ops.weight_format(d)       # 0 fp32, 1 three bf16 planes, 2 two fp16 planes + max |w|, 3 fp32 + max |w|
+        key = tuple((t.data_ptr(), t._version) for t in srcs) + (fmt, str(self.weight.device), epoch)
         hit = self._packed.get("folded")
-        if hit is not None and hit[0] == key:
-            return hit[1]
-        with torch.no_grad():
-            scale = norm.weight.detach() / torch.sqrt(norm.running_var + ops.IN_EPS)
-            shift = (norm.bias.detach() - norm.running_mean * scale).contiguous()
-            wd = (self.weight.detach() * scale.view(-1, 1, 1, 1)).contiguous()
-            wp = (ops.pack_weight_fwd_x3 if x3 else ops.pack_weight_fwd)(wd, geom)
-        self._packed["folded"] = (key, (wp, shift))
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                scale = norm.weight.detach() / torch.sqrt(norm.running_var + ops.IN_EPS)
+                shift = (norm.bias.detach() - norm.running_mean * scale).contiguous()
+                wd = (self.weight.detach() * scale.view(-1, 1, 1, 1)).contiguous()
+                wa = ops.absmax(wd) if fmt >= 2 else None
+                if fmt == 2:
+                    wp = ops.pack_weight_fwd_h2(wd, geom, wa)
+                else:
+                    wp = (ops.pack_weight_fwd_x3 if fmt == 1 else ops.pack_weight_fwd)(wd, geom)
+            hit = (key, (wp, shift, wa))
+            self._packed["folded"] = hit
+        wp, shift, wa = hit[1]
+        if wa is not None:
+            d.w_amax = wa.data_ptr()
         return wp, shift
 
 
@@ -293,9 +300,15 @@ class _GeneratorFn(torch.autograd.Function):
             fuse = nm is not None and not use_running      # statistics ride in the conv's epilogue
             if use_running and inference and ly.kind == "conv" and ly.act_slope <= 1.0:
                 # eval-mode norm folded into the convolution (nothing is kept for a backward pass)
-                # (the folded operands exist as fp32 / bf16 x 3 packs: PREC_F16X2 runs these layers as BF16X3)
-                d = g.fwd_desc(n, a.shape[1], a.shape[2], precision=L.PREC_BF16X3 if h2 else prec, act_slope=ly.act_slope)
+                # (PREC_F16X2: the folded weights are scaled and packed as two fp16 planes, max |input| comes from the
+                # previous layer's epilogue and this layer's epilogue leaves max |output| for the next one)
+                d = g.fwd_desc(n, a.shape[1], a.shape[2], precision=prec, act_slope=ly.act_slope)
                 wp, shift = ly.conv.folded(g, d, nm, mod._stats_epoch)
+                if h2:
+                    if d.w_amax:
+                        d.a_amax = act_amax(li).data_ptr()
+                    ops.set_out_amax(d, amx[li + 1])
+                    amx_ok[li + 1] = True
                 res = acts[li + 1 + ly.res_from] if ly.res_from is not None else None
                 acts.append(ops.conv_gather(d, a, wp, bias=shift, residual=res))
                 saved.append(None)

@@ -145,6 +145,13 @@ def set_amax(d: ConvDesc, a_amax: Optional[torch.Tensor], w_amax: Optional[torch
     return d
 
 
+def set_out_amax(d: ConvDesc, out_amax: Optional[torch.Tensor]) -> ConvDesc:
+    """Ask ``conv_gather`` to leave max |out| in ``out_amax`` (zeroed AMAX_SLOTS floats): the next layer's ``a_amax``."""
+    d.out_amax = _amax_ptr(out_amax)
+    d._out_amax_ref = out_amax
+    return d
+
+
 def set_wgrad_amax(d: WgradDesc, g_amax: Optional[torch.Tensor], x_amax: Optional[torch.Tensor]) -> WgradDesc:
     """PREC_F16X2 weight gradients: device scalars max |gsmall| / max |xbig| (used where the 3x3 halo kernel applies)."""
     d.g_amax = _amax_ptr(g_amax)

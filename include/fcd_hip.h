@@ -87,6 +87,9 @@ typedef struct FcdConvDesc {
   float mask_slope;              /* slope used with mask_src                     */
   const float* a_amax;           /* FCD_PREC_F16X2 only: device scalars max |in| and max |weight| (the powers of two  */
   const float* w_amax;           /* that scale the operands before the fp16 split are derived from them); else NULL */
+  float* out_amax;               /* optional, fcd_conv_gather only, any precision: max |out| of this launch into a zeroed  */
+                                 /* array of FCD_AMAX_SLOTS floats (the next layer's a_amax); from the kernel's epilogue   */
+                                 /* where it writes final values, else by an fcd_absmax pass inside the call; else NULL   */
 } FcdConvDesc;
 
 size_t fcd_conv_workspace_bytes(const FcdConvDesc* d);

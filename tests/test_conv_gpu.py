@@ -730,3 +730,39 @@ def test_wgrad7_halo_f16x2(dev, case):
     assert L.load().fcd_last_conv_kernel().endswith(b"halo_x3_kernel<2>")
     ref = torch.nn.grad.conv2d_weight(x.double(), (O, I, 7, 7), gy.double(), stride=1, padding=3)
     assert relerr(dw.cpu(), ref) <= 1e-6
+
+
+@pytest.mark.parametrize("case", [(256, 256, 3, 1, 1, 8, 32, 32, 2, 0), (128, 64, 4, 2, 1, 4, 64, 64, 2, 0), (10, 64, 7, 1, 3, 2, 64, 64, 2, 0),
+                                  (64, 64, 3, 1, 1, 2, 16, 16, 0, 0), (256, 256, 3, 1, 1, 2, 8, 8, 2, 4), (256, 256, 3, 1, 1, 40, 32, 32, 3, 0)])
+def test_conv_out_amax(dev, case):
+    """FcdConvDesc.out_amax: max |out| of a convolution as FCD_AMAX_SLOTS per-block maxima -- from the epilogue of the
+    32-wide-tile kernels when they write final values, by an fcd_absmax pass inside the call otherwise (halo kernels,
+    split-K, 16-wide tiles); equals torch's abs().max() of the tensor the call wrote, bias / activation / residual
+    included, and accumulates into an array that already holds a maximum."""
+    from fcd_amd import _lib as L, ops
+    O, I, k, st, pd, n, h, w, prec, splitk = case
+    g = ops.ConvGeom(O, I, k, st, pd)
+    gen = torch.Generator().manual_seed(51)
+    x = to_nhwc(torch.randn(n, I, h, w, generator=gen), g.IP).to(dev)
+    wd = (torch.randn(O, I, k, k, generator=gen) / (k * I ** 0.5)).to(dev)
+    d = g.fwd_desc(n, h, w, precision=prec, act_slope=0.2)
+    d.splitk = splitk
+    fmt = ops.weight_format(d)
+    keep = None
+    if fmt >= 2:
+        keep = (ops.absmax(x), ops.absmax(wd))
+        ops.set_amax(d, *keep)
+    wp = {0: ops.pack_weight_fwd, 1: ops.pack_weight_fwd_x3, 3: ops.pack_weight_fwd}[fmt](wd, g) if fmt != 2 else ops.pack_weight_fwd_h2(wd, g, keep[1])
+    oh, ow = g.small_hw(h, w)
+    res = torch.randn(n, oh, ow, g.OP, generator=gen).to(dev)
+    res[..., O:] = 0
+    bias = torch.randn(O, generator=gen).to(dev)
+    am = torch.zeros(ops.AMAX_SLOTS, device=dev)
+    ops.set_out_amax(d, am)
+    out = ops.conv_gather(d, x, wp, bias=bias, residual=res)
+    assert float(am.max()) == float(out.abs().max()) > 0
+    am2 = torch.zeros(ops.AMAX_SLOTS, device=dev)
+    am2[5] = 1e9
+    ops.set_out_amax(d, am2)
+    ops.conv_gather(d, x, wp, bias=bias, residual=res)
+    assert float(am2.max()) == 1e9

@@ -26,9 +26,9 @@ def test_library_exports_every_declared_symbol():
 
 def test_descriptor_structs_match_header_layout():
     from fcd_amd import _lib
-    # sizeof(FcdConvDesc) / sizeof(FcdWgradDesc) of include/fcd_hip.h (gcc, x86-64): 33 ints + padding + 3 pointers;
+    # sizeof(FcdConvDesc) / sizeof(FcdWgradDesc) of include/fcd_hip.h (gcc, x86-64): 33 ints + padding + 4 pointers;
     # 16 ints + 2 pointers
-    assert ctypes.sizeof(_lib.ConvDesc) == 160
+    assert ctypes.sizeof(_lib.ConvDesc) == 168 and _lib.ConvDesc.out_amax.offset == 160
     assert ctypes.sizeof(_lib.WgradDesc) == 80
     assert _lib.ConvDesc.a_amax.offset == 144 and _lib.ConvDesc.w_amax.offset == 152
     assert _lib.WgradDesc.g_amax.offset == 64 and _lib.WgradDesc.x_amax.offset == 72

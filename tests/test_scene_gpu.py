@@ -251,3 +251,29 @@ def test_pseudo_mask_kernel_counts_and_encoding(dev):
     assert np.array_equal(cm.cpu().numpy(), 2 * cm_ref.astype(np.int64))
     out2 = ops.pseudo_mask(torch.from_numpy(d).to(dev), None, thr)                                   # no target: all valid
     assert np.array_equal(out2.cpu().numpy(), pred + 1)
+
+
+@pytest.mark.parametrize("mode", ["fp32", "fp32x3", "fp32x2"])
+def test_eval_difference_map_full_width(dev, mode):
+    """The inference path at the baseline's width (conv_dim 64, 128x128x10, eval mode: InstanceNorm folded into the
+    convolutions; under fp32x2 the folded weights are two fp16 planes and every layer's epilogue leaves max |output|
+    for the next layer's operand scale): the difference map of a batch against the float64 oracle, and the mask
+    against the oracle's away from the threshold."""
+    from fcd_amd import FCDSolver
+    gs = O.synth_generator_state()
+    (x, _, _, _, _), _ = O.synth_batch(2, 128, 10, seed=21)
+    ref = O.difference_map(O.to_dtype(gs, torch.float64), x.double(), training=False)
+    s = FCDSolver(None, precision=mode)
+    s.G.load_state_dict(gs)
+    s.to(dev)
+    s.G.eval()
+    diff, mask = s.difference_and_mask(x.to(dev), 0.02)
+    err = float((diff.cpu().double() - ref).abs().max()) / float(ref.abs().max())
+    assert err <= 2e-6, err
+    far = (ref - 0.02).abs() > 1e-5
+    assert bool((mask.cpu()[far] == (ref > 0.02).to(torch.uint8)[far]).all())
+    # a larger batch takes other tile shapes (256-row tiles, A-halo form): same values per sample
+    xb = x.repeat(16, 1, 1, 1).to(dev)
+    diff32, _ = s.difference_and_mask(xb, 0.02)
+    assert float((diff32[:2] - diff).abs().max()) <= 2e-6 * float(ref.abs().max())
+    assert float((diff32[30:32] - diff).abs().max()) <= 2e-6 * float(ref.abs().max())
