@@ -355,6 +355,150 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const float* __restri
     block_absmax(am, amax, (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, gridDim.x * gridDim.y * gridDim.z);
 }
 
+// InstanceNorm backward in ONE pass for 32 x 32 images (the residual blocks: 34 of the 47 norm backwards of a step).
+// The three-kernel form above reads gy and z twice (sums, then dz) with a finalize launch in between: 167 MB and three
+// launches per 33.5 MB tensor.  Here a workgroup owns (image, 32 channels) = 1024 pixels x 128 bytes of each operand and
+// keeps both slices in registers (1024 threads, 16 float4 each, all loads in flight at once): sums through shuffles and LDS in
+// a fixed order (doubles), then dz straight from the registers -- 100 MB, one launch (plus a tiny one for the affine
+// gradients, which need the sums of all images).  Needs the mask recomputed from z (beta given) or no mask at all, and a
+// (Leaky)ReLU slope: the SiLU / Mish derivatives keep the three-kernel form.
+constexpr int IN1P_HW = 1024, IN1P_J = 8, IN1P_WAVES = 16;      // 128 pixel lanes x 8 channel quads
+__global__ __launch_bounds__(64 * IN1P_WAVES) void in_bwd_onepass_kernel(const float* __restrict__ gy, const float* __restrict__ z,
+                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             float* __restrict__ dz, float* __restrict__ s12, int C,
+                                                             float act_slope, int use_running, unsigned* __restrict__ amax) {
+  __shared__ double wsum[IN1P_WAVES][32][2];       // per wave: (sum g1, sum g1 * xhat) of the workgroup's 32 channels
+  __shared__ float kk[32][2];             // the finished sums / HW
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = blockIdx.y, cq = tid & 7, pl = tid >> 3;
+  const int c0 = blockIdx.x * 32 + 4 * cq;
+  const bool recompute = act_slope != 1.f;
+  float mu[4], rs[4], ga[4], be[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const long nc = (long)n * C + c0 + e;
+    mu[e] = mean[nc];
+    rs[e] = rstd[nc];
+    ga[e] = gamma[c0 + e];
+    be[e] = recompute ? beta[c0 + e] : 0.f;
+  }
+  // buffer addressing: one descriptor per operand on this image (1024 x C floats), one 32-bit lane offset, the 16
+  // pixel groups as scalar offsets -- 64-bit per-load addresses would cost 64 registers and spill
+  const size_t img = (size_t)n * IN1P_HW * C * 4;
+  const int img_bytes = IN1P_HW * C * 4;
+  __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((char*)gy + img, (short)0, img_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc((char*)z + img, (short)0, img_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((char*)dz + img, (short)0, img_bytes, 0x00020000);
+  const int voff = (pl * C + c0) * 4, jstep = 128 * C * 4;
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+  float4 g[IN1P_J], zz[IN1P_J];
+#pragma unroll
+  for (int j = 0; j < IN1P_J; ++j) g[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rg, voff, j * jstep, 0));
+#pragma unroll
+  for (int j = 0; j < IN1P_J; ++j) zz[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rz, voff, j * jstep, 0));
+  // g <- g1 = gy * act'(.), zz <- xhat; per-thread sums over its 8 pixels
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < IN1P_J; ++j) {
+    float gv[4] = {g[j].x, g[j].y, g[j].z, g[j].w}, zv[4] = {zz[j].x, zz[j].y, zz[j].z, zz[j].w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float yv = recompute ? in_forward_value(zv[e], mu[e], rs[e], ga[e], be[e]) : 1.f;
+      gv[e] *= yv > 0.f ? 1.f : act_slope;          // slopes in [0, 1] only (the host routes SiLU / Mish elsewhere)
+      zv[e] = (zv[e] - mu[e]) * rs[e];
+      s1[e] += gv[e];
+      s2[e] += gv[e] * zv[e];
+    }
+    g[j] = make_float4(gv[0], gv[1], gv[2], gv[3]);
+    zz[j] = make_float4(zv[0], zv[1], zv[2], zv[3]);
+  }
+  // lanes l, l + 8, ..., l + 56 of a wave share a channel quad: xor tree over lane bits 3..5, then the 16 waves in order
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    double d1 = (double)s1[e], d2 = (double)s2[e];
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) {
+      d1 += __shfl_xor(d1, o);
+      d2 += __shfl_xor(d2, o);
+    }
+    if (lane < 8) {
+      wsum[wave][4 * cq + e][0] = d1;
+      wsum[wave][4 * cq + e][1] = d2;
+    }
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const int c = tid & 31, w = tid >> 5;
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < IN1P_WAVES; ++k) t += wsum[k][c][w];
+    s12[((long)n * C + blockIdx.x * 32 + c) * 2 + w] = (float)t;
+    kk[c][w] = use_running ? 0.f : (float)t * (1.f / (float)IN1P_HW);
+  }
+  __syncthreads();
+  float k0[4], k1[4], k2[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    k0[e] = ga[e] * rs[e];
+    // (the three-kernel form rounds the sum to fp32 before the division by HW: same here)
+    k1[e] = kk[4 * cq + e][0];
+    k2[e] = kk[4 * cq + e][1];
+  }
+  float am = 0.f;
+#pragma unroll
+  for (int j = 0; j < IN1P_J; ++j) {
+    const float gv[4] = {g[j].x, g[j].y, g[j].z, g[j].w}, xh[4] = {zz[j].x, zz[j].y, zz[j].z, zz[j].w};
+    float o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = k0[e] * (gv[e] - k1[e] - xh[e] * k2[e]);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, make_float4(o[0], o[1], o[2], o[3])), rd, voff, j * jstep, 0);
+    am = fmaxf(fmaxf(fmaxf(am, fabsf(o[0])), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3])));
+  }
+  if (amax) {
+    // (block_absmax is written for 4 waves: the same scheme for 16)
+    __shared__ float wmax[IN1P_WAVES];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o));
+    if (lane == 0) wmax[wave] = am;
+    __syncthreads();
+    if (tid == 0) {
+      float m = 0.f;
+#pragma unroll
+      for (int k = 0; k < IN1P_WAVES; ++k) m = fmaxf(m, wmax[k]);
+      const unsigned b = __float_as_uint(m), blocks = gridDim.x * gridDim.y;
+      unsigned* slot = amax + ((blockIdx.y * gridDim.x + blockIdx.x) & (FCD_AMAX_SLOTS - 1));
+      if (blocks <= FCD_AMAX_SLOTS) {
+        if (b > *slot) *slot = b;
+      } else if (b > __builtin_nontemporal_load(slot)) {
+        atomicMax(slot, b);
+      }
+    }
+  }
+}
+
+// dgamma / dbeta from s12[n][c] = (sum g1, sum g1 * xhat): sums over the images in double, in image order
+__global__ __launch_bounds__(256) void affine_from_s12_kernel(const float* __restrict__ s12, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, int N, int C, int accumulate) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double a = 0.0, b = 0.0;
+  for (int i0 = 0; i0 < N; i0 += 16) {
+    float2 v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+      if (i0 + u < N) v[u] = *reinterpret_cast<const float2*>(s12 + ((long)(i0 + u) * C + c) * 2);
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+      if (i0 + u < N) {
+        b += (double)v[u].x;
+        a += (double)v[u].y;
+      }
+  }
+  if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)a : (float)a;
+  if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)b : (float)b;
+}
+
 __global__ __launch_bounds__(256) void stats_from_running_kernel(const float* __restrict__ rm, const float* __restrict__ rv,
                                                                  float* __restrict__ mean, float* __restrict__ rstd, int N,
                                                                  int C, float eps) {
@@ -628,6 +772,17 @@ extern "C" int fcd_instnorm_bwd_amax(const float* gy, const float* y, const floa
   hipStream_t st = fcd_stream(stream);
   double* partial = (double*)workspace;
   float* s12 = (float*)((char*)workspace + pb);
+  if (HW == IN1P_HW && C % 32 == 0 && act_slope <= 1.f && (beta || act_slope == 1.f) && (long)N * (C / 32) >= 64 &&
+      !getenv("FCD_NO_IN1P")) {
+    // one pass: (image, 32 channels) per workgroup, both operand slices in registers
+    hipLaunchKernelGGL(in_bwd_onepass_kernel, dim3(C / 32, N), dim3(64 * IN1P_WAVES), 0, st, gy, z, mean, rstd, gamma, beta, dz, s12, C,
+                       act_slope, use_running, (unsigned*)dz_amax);
+    rc = fcd_check_launch("instnorm_bwd/onepass");
+    if (rc || !(dgamma || dbeta)) return rc;
+    hipLaunchKernelGGL(affine_from_s12_kernel, dim3(fcd_cdiv(C, 256)), dim3(256), 0, st, (const float*)s12, dgamma, dbeta, N, C,
+                       accumulate);
+    return fcd_check_launch("instnorm_bwd/affine");
+  }
   const size_t shm = (size_t)pl.rows * pl.c4b * 4 * 2 * sizeof(double);
   hipLaunchKernelGGL((col_partial_kernel<MODE_BWD>), dim3(pl.chunks, N, pl.cblocks), dim3(256), shm, st, gy, y, z, mean, rstd,
                      partial, (long)HW, C, pl, act_slope, gamma, beta);

@@ -294,3 +294,41 @@ def test_instnorm_stats_large_mean(dev, ratio):
         assert relerr(out, z) <= 1e-6
         assert relerr(mean_f, mo) <= 1e-6
         assert float(((rstd_f.cpu().double() - (vo + 1e-5).rsqrt()) / (vo + 1e-5).rsqrt()).abs().max()) <= 1e-5, prec
+
+
+@pytest.mark.parametrize("case", [(32, 64, 0.0, False), (5, 512, 0.2, False), (33, 96, 1.0, False), (32, 64, 0.0, True)])
+def test_instnorm_backward_one_pass(dev, case, monkeypatch):
+    """InstanceNorm backward of 32 x 32 images (the residual blocks) in one pass -- a workgroup per (image, 32 channels)
+    with both operand slices in registers -- against torch in float64, against the three-kernel form (FCD_NO_IN1P=1:
+    same sums up to their order), with accumulation into existing affine gradients and with the fused max |dz|."""
+    from fcd_amd import ops
+    n, c, slope, use_running = case
+    torch.manual_seed(3)
+    z = (torch.randn(n, c, 32, 32) * 2 + 0.5).double().requires_grad_(True)
+    gamma = (1 + 0.2 * torch.randn(c)).double().requires_grad_(True)
+    beta = (0.2 * torch.randn(c)).double().requires_grad_(True)
+    gy = torch.randn(n, c, 32, 32).double() * 1e-2
+    rm, rv = torch.randn(c).double() * 0.1 + 0.5, torch.rand(c).double() + 3.5
+    if use_running:
+        y0 = F.instance_norm(z, rm.clone(), rv.clone(), gamma, beta, False, 0.1, 1e-5)
+    else:
+        y0 = F.instance_norm(z, None, None, gamma, beta, True, 0.1, 1e-5)
+    F.leaky_relu(y0, slope).backward(gy)
+    zd, gd = nhwc(z.detach().float()).to(dev), nhwc(gy.float()).to(dev)
+    gam, bet = gamma.detach().float().to(dev), beta.detach().float().to(dev)
+    if use_running:
+        mean, rstd = ops.instnorm_stats_from_running(rm.float().to(dev), rv.float().to(dev), n)
+    else:
+        mean, rstd, _ = ops.instnorm_stats(zd)
+    am = torch.zeros(ops.AMAX_SLOTS, device=dev)
+    dz, dg, db = ops.instnorm_bwd(gd, None, zd, mean, rstd, gam, slope, use_running, beta=bet, dz_amax=am)
+    assert relerr(dz.cpu(), nhwc(z.grad)) <= 2e-5
+    assert relerr(dg, gamma.grad) <= 2e-5 and relerr(db, beta.grad) <= 2e-5
+    assert float(am.max()) == float(dz.abs().max())
+    monkeypatch.setenv("FCD_NO_IN1P", "1")
+    dz3, dg3, db3 = ops.instnorm_bwd(gd, None, zd, mean, rstd, gam, slope, use_running, beta=bet)
+    monkeypatch.delenv("FCD_NO_IN1P")
+    assert relerr(dz, dz3) <= 1e-6 and relerr(dg, dg3) <= 1e-6 and relerr(db, db3) <= 1e-6
+    acc_g, acc_b = torch.full_like(dg, 2.0), torch.full_like(db, -1.0)
+    ops.instnorm_bwd(gd, None, zd, mean, rstd, gam, slope, use_running, beta=bet, dgamma=acc_g, dbeta=acc_b, accumulate=True)
+    assert relerr(acc_g - 2.0, dg) <= 1e-5 and relerr(acc_b + 1.0, db) <= 1e-5
