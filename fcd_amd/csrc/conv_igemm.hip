@@ -86,7 +86,13 @@ struct WgradArgs {
 // channels; ic = 64, or 256 for the widest layers, whose 32768 blocks of 4 KB were launch-bound): slab rows are
 // read along i (coalesced), summed over the splits in a fixed order, transposed through LDS and written as one
 // contiguous run of ic*taps floats.
-static int wr_ic(int I) { return I >= 1024 ? 256 : 64; }
+static int wr_ic(int O, int I) {
+  int ic = I >= 1024 ? 256 : 64;
+  // few output channels (the 7x7 layers: O = 10 -> 10 blocks walking 256 slabs each, 45 us): narrower channel chunks
+  // until the grid covers the chip; the order of the sum over the slabs does not change
+  while (ic > 4 && (long)O * ((I + ic - 1) / ic) < 256) ic /= 2;
+  return ic;
+}
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs p, const int WR_IC) {
   extern __shared__ float wr_tile[];   // [WR_IC][taps | 1] (odd row stride: no bank conflicts)
   const int taps = p.KH * p.KW, tp = taps | 1;
@@ -3634,7 +3640,7 @@ extern "C" int fcd_conv_wgrad(const FcdWgradDesc* d, const float* gsmall, const 
     rc = launch_wgrad<256, 128, 4, 2>(a, d->precision, st);
   }
   if (rc) return rc;
-  const int ic = wr_ic(d->I);
+  const int ic = wr_ic(d->O, d->I);
   const int blocks = d->O * fcd_cdiv(d->I, ic);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), (size_t)ic * (d->KH * d->KW | 1) * sizeof(float), st, a, ic);
   return fcd_check_launch("wgrad_reduce");
