@@ -447,9 +447,10 @@ def main():
                "dtype": {"fp32": "fp32", "bf16": "bf16 operands, fp32 accumulate",
                          "fp32x3": "fp32 (conv operands as 3 bf16 pieces on the bf16 MFMA pipe, fp32 accumulate; "
                                    "fp32-faithful: same parity bars as exact fp32)",
-                         "fp32x2": "fp32 (conv operands as 3 bf16 pieces, or - 3x3 residual-block layers - 2 fp16 pieces of "
-                                   "the power-of-two-scaled values, on the 16-bit MFMA pipe, fp32 accumulate; fp32-faithful: "
-                                   "measured error vs fp64 below the exact-fp32 MFMA chain's, same parity bars)"}[args.precision],
+                         "fp32x2": "fp32 (conv operands on the 16-bit MFMA pipe, fp32 accumulate: generator layers as 2 fp16 "
+                                   "pieces of the power-of-two-scaled values, 3 MFMAs per product group; discriminator as 3 bf16 "
+                                   "pieces, 6 MFMAs; fp32-faithful: measured error vs fp64 below the exact-fp32 MFMA chain's, "
+                                   "same parity bars)"}[args.precision],
                "data": "synthetic (numpy PCG64 uint16 patches -> [-1,1], nodata rectangle; random-init weights)",
                "config": {"workload": "FCD G+D train step incl. gradient penalty, batch 16/GPU, 128x128x10, "
                                       "6 res blocks, D x6 (BASELINE.json configs[1])",
