@@ -240,3 +240,35 @@ def test_training_is_bitwise_reproducible(full):
         return h.hexdigest()
 
     assert run() == run()
+
+
+@pytest.mark.parametrize("act", ["silu", "mish"])
+def test_full_width_smooth_networks_fp32x2(dev, act):
+    """Full-width networks with a smooth activation in both (fixed_point_gan.py:13-16) under fp32x2: the activation
+    codes travel through the fused max |.| producers (InstanceNorm apply with amax; the smooth derivatives keep the
+    three-kernel InstanceNorm backward); the G-step's parameter gradients of fp32x2 against fp32x3 and of both against
+    the exact-fp32 mode of the same library."""
+    from fcd_amd import FCDSolver
+    from fcd_amd.synth import synth_batch
+    batch, _ = synth_batch(8, 128, 10, seed=17)
+    b = tuple(t.to(dev) for t in batch)
+    grads = {}
+    for mode in ("fp32", "fp32x3", "fp32x2"):
+        torch.manual_seed(11)
+        s = FCDSolver(None, act_G=act, act_D=act, batch_size=8, precision=mode).to(dev)
+        s.D.requires_grad_(False)
+        s.global_step = s.n_critic - 1
+        loss = s.training_step(b, 0, 1)
+        loss.backward()
+        assert torch.isfinite(loss)
+        grads[mode] = {k: p.grad.detach().double().cpu() for k, p in s.G.named_parameters()}
+    def worst(a, b_):
+        return max(float((grads[a][k] - g).norm() / (g.norm() + 1e-30)) for k, g in grads[b_].items())
+
+    w = {"x2_vs_x3": worst("fp32x2", "fp32x3"), "x2_vs_fp32": worst("fp32x2", "fp32"), "x3_vs_fp32": worst("fp32x3", "fp32")}
+    print("smooth", act, "worst rel. difference of G-step gradients between modes:", w)
+    # random-init networks are ill-conditioned (DESIGN section 2) and the L1 terms of the G loss keep their sign kinks:
+    # measured 1e-4 .. 1.2e-3 between any two of the three modes, with a different mode the outlier for SiLU and for
+    # Mish -- what this test pins is that the smooth-activation plumbing of fp32x2 runs at full width and lands in the
+    # same band
+    assert max(w.values()) <= 5e-3, w

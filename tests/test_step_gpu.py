@@ -354,7 +354,7 @@ def _backward(s, loss, optimizer_idx, arena):
 
 
 @pytest.mark.parametrize("name", list(VARIANTS))
-@pytest.mark.parametrize("prec", ["fp32", "fp32x3", "fp32-arena"])
+@pytest.mark.parametrize("prec", ["fp32", "fp32x3", "fp32x2", "fp32-arena", "fp32x2-arena"])
 def test_variant_steps(dev, tiny, name, prec):
     """prec 'fp32-arena': gradients accumulated by the kernels straight into the flat arenas
     (the training path) instead of being returned through autograd."""
