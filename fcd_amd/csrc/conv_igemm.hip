@@ -3362,9 +3362,19 @@ extern "C" size_t fcd_conv_gather_stats_workspace_bytes(const FcdConvDesc* d) {
   return conv + stats;
 }
 
-extern "C" int fcd_conv_gather_stats(const FcdConvDesc* d, const float* in, const float* w_packed, float* out,
-                                     float* mean, float* rstd, float* var_unbiased, float eps, void* workspace,
-                                     size_t workspace_bytes, void* stream) {
+namespace {
+// apply != nullptr: normalise + affine + activation (+ residual) into apply->y as well (fcd_conv_gather_stats_apply)
+struct StatsApply {
+  const float* gamma;
+  const float* beta;
+  const float* residual;
+  float* y;
+  float act_slope;
+  float* y_amax;
+};
+int conv_stats_impl(const FcdConvDesc* d, const float* in, const float* w_packed, float* out, float* mean, float* rstd,
+                    float* var_unbiased, float eps, const StatsApply* apply, void* workspace, size_t workspace_bytes,
+                    void* stream) {
   FCD_REQUIRE(d != nullptr, "conv_stats: null descriptor");
   const FcdConvDesc* d_orig = d;
   const NormDesc nd = normalise(d);
@@ -3398,15 +3408,41 @@ extern "C" int fcd_conv_gather_stats(const FcdConvDesc* d, const float* in, cons
   if (chunks == 0) {   // shape does not allow the fused form: convolution, then the two-pass statistics
     rc = run_gather(d, a, st);
     if (rc) return rc;
-    return fcd_instnorm_stats(out, mean, rstd, var_unbiased, d->N, (int)hw, d->CoutP, eps, stats_ws,
-                              workspace_bytes - conv_ws, stream);
+    rc = fcd_instnorm_stats(out, mean, rstd, var_unbiased, d->N, (int)hw, d->CoutP, eps, stats_ws,
+                            workspace_bytes - conv_ws, stream);
+    if (rc || !apply) return rc;
+    return fcd_instnorm_apply_amax(out, mean, rstd, apply->gamma, apply->beta, apply->residual, apply->y, d->N, (int)hw,
+                                   d->CoutP, apply->act_slope, apply->y_amax, stream);
   }
   a.stats = (double*)stats_ws;
   a.stats_cpp = chunks / d->nphase;
   rc = run_gather(d, a, st);
   if (rc) return rc;
-  return fcd_finalize_stats((const double*)stats_ws, mean, rstd, var_unbiased, d->N, hw, d->CoutP, chunks, eps, st);
+  if (!apply) return fcd_finalize_stats((const double*)stats_ws, mean, rstd, var_unbiased, d->N, hw, d->CoutP, chunks, eps, st);
+  return fcd_finalize_apply((const double*)stats_ws, out, mean, rstd, var_unbiased, d->N, hw, d->CoutP, chunks, eps,
+                            apply->gamma, apply->beta, apply->residual, apply->y, apply->act_slope, apply->y_amax, st);
 }
+}  // namespace
+
+extern "C" int fcd_conv_gather_stats(const FcdConvDesc* d, const float* in, const float* w_packed, float* out,
+                                     float* mean, float* rstd, float* var_unbiased, float eps, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+  return conv_stats_impl(d, in, w_packed, out, mean, rstd, var_unbiased, eps, nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int fcd_conv_gather_stats_apply(const FcdConvDesc* d, const float* in, const float* w_packed, float* z,
+                                           float* mean, float* rstd, float* var_unbiased, float eps, const float* gamma,
+                                           const float* beta, const float* residual, float* y, float act_slope,
+                                           float* y_amax, void* workspace, size_t workspace_bytes, void* stream) {
+  FCD_REQUIRE(gamma && beta && y, "conv_stats_apply: null tensor");
+  FCD_REQUIRE((act_slope >= 0.f && act_slope <= 1.f) || act_slope == FCD_ACT_SILU || act_slope == FCD_ACT_MISH,
+              "conv_stats_apply: act_slope %g is neither a slope in [0,1] nor an activation code", act_slope);
+  FCD_REQUIRE(y != z && (const float*)y != in, "conv_stats_apply: y must not alias z or the input");
+  const StatsApply ap = {gamma, beta, residual, y, act_slope, y_amax};
+  return conv_stats_impl(d, in, w_packed, z, mean, rstd, var_unbiased, eps, &ap, workspace, workspace_bytes, stream);
+}
+
+
 
 // The halo form of the 7x7, <= 16-output-channel weight gradient: number of split slabs it writes
 // (0 = not applicable), rows per workgroup, row ranges and column strips.

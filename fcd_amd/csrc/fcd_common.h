@@ -15,6 +15,10 @@ void fcd_set_error(const char* fmt, ...);
 // (used by the convolution's fused-statistics entry point in conv_igemm.hip).
 int fcd_finalize_stats(const double* partial, float* mean, float* rstd, float* var_unbiased, int N, long HW, int C,
                        int chunks, float eps, hipStream_t st);
+// norm.hip: the same, followed by normalise + affine + activation (+ residual) of z into y; one launch for 32 x 32 images
+int fcd_finalize_apply(const double* partial, const float* z, float* mean, float* rstd, float* var_unbiased, int N, long HW,
+                       int C, int chunks, float eps, const float* gamma, const float* beta, const float* residual, float* y,
+                       float act_slope, float* y_amax, hipStream_t st);
 
 // norm.hip: resolves the current device's copy of the built-in scratch array of
 // fcd_instnorm_stats_noalloc (hipGetSymbolAddress, once per device; `device` must be current).

@@ -241,8 +241,11 @@ def conv_gather(d: ConvDesc, x: torch.Tensor, w_packed: torch.Tensor, bias=None,
     return out
 
 
-def conv_gather_stats(d: ConvDesc, x: torch.Tensor, w_packed: torch.Tensor, want_var: bool = False):
-    """Convolution + InstanceNorm statistics of its output: ``(z, mean, rstd, var_unbiased)``."""
+def conv_gather_stats(d: ConvDesc, x: torch.Tensor, w_packed: torch.Tensor, want_var: bool = False, apply=None):
+    """Convolution + InstanceNorm statistics of its output: ``(z, mean, rstd, var_unbiased)``.
+
+    ``apply=(gamma, beta, act_slope, residual, amax)``: also the norm's output ``y = act(IN(z)) (+ residual)`` and, with
+    ``amax`` (zeroed AMAX_SLOTS-element tensor), ``max |y|``; returns ``(z, mean, rstd, var_unbiased, y)``."""
     lib = L.load()
     exp_in = (d.N, d.IH, d.IW, d.Cin)
     if tuple(x.shape) != exp_in:
@@ -258,12 +261,25 @@ def conv_gather_stats(d: ConvDesc, x: torch.Tensor, w_packed: torch.Tensor, want
     if timed:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(lib.fcd_conv_gather_stats(C.byref(d), ptr(x), ptr(w_packed), ptr(out), ptr(mean), ptr(rstd), ptr(varu), IN_EPS,
-                                    wp, wn, stream()), "conv_gather_stats")
+    if apply is None:
+        check(lib.fcd_conv_gather_stats(C.byref(d), ptr(x), ptr(w_packed), ptr(out), ptr(mean), ptr(rstd), ptr(varu), IN_EPS,
+                                        wp, wn, stream()), "conv_gather_stats")
+    else:
+        gamma, beta, act_slope, residual, amax = apply
+        if gamma.numel() != d.CoutP or beta.numel() != d.CoutP:
+            raise RuntimeError(f"conv_gather_stats: gamma / beta must have {d.CoutP} elements")
+        if residual is not None and tuple(residual.shape) != tuple(out.shape):
+            raise RuntimeError(f"conv_gather_stats: residual {tuple(residual.shape)} != output {tuple(out.shape)}")
+        y = torch.empty_like(out)
+        check(lib.fcd_conv_gather_stats_apply(C.byref(d), ptr(x), ptr(w_packed), ptr(out), ptr(mean), ptr(rstd), ptr(varu),
+                                              IN_EPS, ptr(gamma), ptr(beta), ptr(residual), ptr(y), act_slope,
+                                              _amax_ptr(amax), wp, wn, stream()), "conv_gather_stats_apply")
     if timed:       # includes the (few microseconds) finalize kernel that follows the convolution
         e1.record()
         KERNEL_TIMER.pairs.append((e0, e1))
         KERNEL_TIMER.note(timed, d)
+    if apply is not None:
+        return out, mean, rstd, varu, y
     return out, mean, rstd, varu
 
 

@@ -113,6 +113,18 @@ int fcd_conv_gather_stats(const FcdConvDesc* d, const float* in, const float* w_
                           float* mean, float* rstd, float* var_unbiased, float eps, void* workspace,
                           size_t workspace_bytes, void* stream);
 
+/* The same followed by the norm's own output: y = act((z - mean) * rstd * gamma + beta) (+ residual), and max |y| into
+ * y_amax if not NULL (fcd_instnorm_apply_amax) -- Conv2d + InstanceNorm2d + activation of fixed_point_gan.py:27-29, 30-34
+ * (the residual block: y = x + IN(conv(...))), 45-47, 52-54, 63-65.  z (the raw convolution output, kept for the backward
+ * pass), mean, rstd and var_unbiased are written as by fcd_conv_gather_stats; results are bit-identical to
+ * fcd_conv_gather_stats + fcd_instnorm_apply_amax.  For 32 x 32 outputs with fused statistics and a (Leaky)ReLU slope the
+ * statistics are finished inside the normalising kernel (one launch after the convolution instead of two; switch
+ * FCD_NO_IN1F=1 for A/B runs).  Workspace as fcd_conv_gather_stats_workspace_bytes.  y must not alias z or in. */
+int fcd_conv_gather_stats_apply(const FcdConvDesc* d, const float* in, const float* w_packed, float* z,
+                                float* mean, float* rstd, float* var_unbiased, float eps, const float* gamma,
+                                const float* beta, const float* residual, float* y, float act_slope,
+                                float* y_amax, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Weight gradient of the same convolution family:
  *   dw[o][i][kh][kw] (+)= sum_{n,a,b} gsmall[n,a,b,o] *
  *                          xbig[n, a*stride - pad + kh, b*stride - pad + kw, i]

@@ -157,6 +157,69 @@ def test_conv_with_fused_instnorm_statistics(dev, geom, prec):
     assert relerr(v1, zc.var((1, 2), unbiased=True)) <= 1e-5
 
 
+APPLY_GEOMS = [
+    # O, I, k, s, p, N, H, W, form, act_slope, residual
+    (256, 256, 3, 1, 1, 8, 32, 32, "fwd", 0.0, False),     # residual block, first half: one-pass kernel
+    (256, 256, 3, 1, 1, 8, 32, 32, "fwd", 1.0, True),      # second half: no activation, + residual
+    (64, 64, 3, 1, 1, 33, 32, 32, "fwd", 0.2, True),       # odd image count, LeakyReLU
+    (256, 128, 4, 2, 1, 8, 64, 64, "fwd", 0.0, False),     # strided layer onto 32 x 32
+    (64, 128, 4, 2, 1, 4, 32, 32, "adj", 0.0, False),      # 64 x 64 output: finalize + apply
+    (256, 256, 3, 1, 1, 4, 32, 32, "fwd", "silu", False),  # smooth activation: finalize + apply
+    (96, 40, 3, 1, 1, 1, 9, 7, "fwd", 0.0, True),          # ragged: two-pass statistics + apply
+    (32, 32, 3, 1, 1, 1, 32, 32, "fwd", 0.0, False),       # too few workgroups for the one-pass form
+]
+
+
+@pytest.mark.parametrize("prec", [0, 2])
+@pytest.mark.parametrize("geom", APPLY_GEOMS)
+def test_conv_stats_apply_in_one_call(dev, geom, prec, monkeypatch):
+    """fcd_conv_gather_stats_apply == fcd_conv_gather_stats followed by fcd_instnorm_apply_amax, bit for bit (the one-pass
+    kernel finishes the statistics in finalize_kernel's order), with FCD_NO_IN1F=1 as well, and y against torch."""
+    from fcd_amd import ops
+    O, I, k, s, p, N, H, W, form, slope, with_res = geom
+    if slope == "silu":
+        slope = ops.ACT_SILU
+    g = ops.ConvGeom(O, I, k, s, p)
+    torch.manual_seed(6)
+    w = torch.randn(O, I, k, k) / (I * k * k) ** 0.5
+    if form == "fwd":
+        x = to_nhwc(torch.randn(N, I, H, W) + 0.3, g.IP).to(dev)
+        d = g.fwd_desc(N, H, W, precision=prec)
+        wp = pack_for(d, w.to(dev), g, "fwd")
+        cout = g.OP
+    else:
+        x = to_nhwc(torch.randn(N, O, H, W) + 0.3, g.OP).to(dev)
+        d = g.adj_desc(N, H, W, precision=prec)
+        wp = pack_for(d, w.to(dev), g, "adj")
+        cout = g.IP
+    gamma = (1 + 0.2 * torch.randn(cout)).to(dev)
+    beta = (0.2 * torch.randn(cout)).to(dev)
+    z0, m0, r0, v0 = ops.conv_gather_stats(d, x, wp, want_var=True)
+    res = torch.randn_like(z0) if with_res else None
+    am0 = torch.zeros(ops.AMAX_SLOTS, device=dev)
+    y0 = ops.instnorm_apply(z0, m0, r0, gamma, beta, slope, residual=res, amax=am0)
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("FCD_NO_IN1F", "1")
+        am1 = torch.zeros(ops.AMAX_SLOTS, device=dev)
+        z1, m1, r1, v1, y1 = ops.conv_gather_stats(d, x, wp, want_var=True, apply=(gamma, beta, slope, res, am1))
+        assert torch.equal(z0, z1) and torch.equal(m0, m1) and torch.equal(r0, r1) and torch.equal(v0, v1)
+        assert torch.equal(y0, y1)
+        assert float(am1.max()) == float(y1.abs().max()) == float(am0.max())
+        # without the unbiased variance and the maximum
+        _, m2, _, v2, y2 = ops.conv_gather_stats(d, x, wp, apply=(gamma, beta, slope, None, None))
+        assert v2 is None and torch.equal(m2, m0)
+        if res is None:
+            assert torch.equal(y2, y0)
+    zc = z0.cpu().double()
+    mu, var = zc.mean((1, 2), keepdim=True), zc.var((1, 2), unbiased=False, keepdim=True)
+    ref = (zc - mu) / (var + 1e-5).sqrt() * gamma.cpu().double() + beta.cpu().double()
+    ref = F.silu(ref) if slope == ops.ACT_SILU else F.leaky_relu(ref, slope)
+    if res is not None:
+        ref = ref + res.cpu().double()
+    assert relerr(y0.cpu(), ref) <= 1e-5
+
+
 # 7x7 / <= 16 output channels / input channels a multiple of 16: the halo weight-gradient kernel
 # (input rows loaded once for all 49 taps).  Ragged widths (column strips with out-of-range halo),
 # heights that do not divide into the row ranges, 3 / 10 / 16 output channels, accumulation.
