@@ -91,6 +91,8 @@ PROTOTYPES = {
     "fcd_absmax": (_I, [_P, _Z, _P, _P]),
     "fcd_instnorm_apply_amax": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P]),
     "fcd_instnorm_bwd_amax": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P, _P, _Z, _P]),
+    "fcd_instnorm_bwd_s12": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _P, _P, _Z, _P]),
+    "fcd_instnorm_affine_batch": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "fcd_g_prologue": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "fcd_g_epilogue_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "fcd_g_epilogue_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),

@@ -623,6 +623,36 @@ __global__ __launch_bounds__(256) void affine_from_s12_kernel(const float* __res
   if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)b : (float)b;
 }
 
+// affine_from_s12_kernel for up to FCD_AFFINE_BATCH_MAX norms of one backward pass in one launch (blockIdx.y = norm):
+// same sums in the same order
+struct AffineBatch {
+  const float* s12[FCD_AFFINE_BATCH_MAX];
+  float* dgamma[FCD_AFFINE_BATCH_MAX];
+  float* dbeta[FCD_AFFINE_BATCH_MAX];
+};
+__global__ __launch_bounds__(256) void affine_batch_kernel(const AffineBatch bt, int N, int C, int accumulate) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float* __restrict__ s12 = bt.s12[blockIdx.y];
+  float* __restrict__ dgamma = bt.dgamma[blockIdx.y];
+  float* __restrict__ dbeta = bt.dbeta[blockIdx.y];
+  double a = 0.0, b = 0.0;
+  for (int i0 = 0; i0 < N; i0 += 16) {
+    float2 v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+      if (i0 + u < N) v[u] = *reinterpret_cast<const float2*>(s12 + ((long)(i0 + u) * C + c) * 2);
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+      if (i0 + u < N) {
+        b += (double)v[u].x;
+        a += (double)v[u].y;
+      }
+  }
+  if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)a : (float)a;
+  if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)b : (float)b;
+}
+
 __global__ __launch_bounds__(256) void stats_from_running_kernel(const float* __restrict__ rm, const float* __restrict__ rv,
                                                                  float* __restrict__ mean, float* __restrict__ rstd, int N,
                                                                  int C, float eps) {
@@ -893,10 +923,13 @@ extern "C" int fcd_instnorm_bwd(const float* gy, const float* y, const float* z,
                                use_running, nullptr, workspace, workspace_bytes, stream);
 }
 
-extern "C" int fcd_instnorm_bwd_amax(const float* gy, const float* y, const float* z, const float* mean, const float* rstd,
-                                     const float* gamma, const float* beta, float* dz, float* dgamma, float* dbeta,
-                                     int accumulate, int N, int HW, int C, float act_slope, int use_running,
-                                     float* dz_amax, void* workspace, size_t workspace_bytes, void* stream) {
+namespace {
+// s12_out given: the per-image sums go there instead of the workspace and no affine gradient is computed (the caller
+// sums them later: fcd_instnorm_affine_batch)
+int instnorm_bwd_impl(const float* gy, const float* y, const float* z, const float* mean, const float* rstd,
+                      const float* gamma, const float* beta, float* dz, float* dgamma, float* dbeta, int accumulate, int N,
+                      int HW, int C, float act_slope, int use_running, float* dz_amax, float* s12_out, void* workspace,
+                      size_t workspace_bytes, void* stream) {
   int rc = check_nhwc("instnorm_bwd", N, HW, C);
   if (rc) return rc;
   FCD_REQUIRE(gy && z && mean && rstd && gamma && dz, "instnorm_bwd: null tensor");
@@ -912,7 +945,7 @@ extern "C" int fcd_instnorm_bwd_amax(const float* gy, const float* y, const floa
   ColPlan pl = col_plan(N, HW, C);
   hipStream_t st = fcd_stream(stream);
   double* partial = (double*)workspace;
-  float* s12 = (float*)((char*)workspace + pb);
+  float* s12 = s12_out ? s12_out : (float*)((char*)workspace + pb);
   if (HW == IN1P_HW && C % 32 == 0 && act_slope <= 1.f && (beta || act_slope == 1.f) && (long)N * (C / 32) >= 64 &&
       !getenv("FCD_NO_IN1P")) {
     // one pass: (image, 32 channels) per workgroup, both operand slices in registers
@@ -936,6 +969,39 @@ extern "C" int fcd_instnorm_bwd_amax(const float* gy, const float* y, const floa
   hipLaunchKernelGGL(in_bwd_apply_kernel, dim3(pl.chunks, N, pl.cblocks), dim3(256), 0, st, gy, y, z, mean, rstd, gamma, s12,
                      dz, (long)HW, C, pl, act_slope, use_running, beta, dgamma, dbeta, N, accumulate, (unsigned*)dz_amax);
   return fcd_check_launch("instnorm_bwd/apply");
+}
+}  // namespace
+
+extern "C" int fcd_instnorm_bwd_amax(const float* gy, const float* y, const float* z, const float* mean, const float* rstd,
+                                     const float* gamma, const float* beta, float* dz, float* dgamma, float* dbeta,
+                                     int accumulate, int N, int HW, int C, float act_slope, int use_running,
+                                     float* dz_amax, void* workspace, size_t workspace_bytes, void* stream) {
+  return instnorm_bwd_impl(gy, y, z, mean, rstd, gamma, beta, dz, dgamma, dbeta, accumulate, N, HW, C, act_slope, use_running,
+                           dz_amax, nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int fcd_instnorm_bwd_s12(const float* gy, const float* y, const float* z, const float* mean, const float* rstd,
+                                    const float* gamma, const float* beta, float* dz, float* s12, int N, int HW, int C,
+                                    float act_slope, int use_running, float* dz_amax, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+  FCD_REQUIRE(s12 != nullptr, "instnorm_bwd_s12: null s12");
+  return instnorm_bwd_impl(gy, y, z, mean, rstd, gamma, beta, dz, nullptr, nullptr, 0, N, HW, C, act_slope, use_running,
+                           dz_amax, s12, workspace, workspace_bytes, stream);
+}
+
+extern "C" int fcd_instnorm_affine_batch(const float* const* s12, float* const* dgamma, float* const* dbeta, int count,
+                                         int N, int C, int accumulate, void* stream) {
+  FCD_REQUIRE(s12 && dgamma && dbeta, "affine_batch: null array");
+  FCD_REQUIRE(count >= 1 && count <= FCD_AFFINE_BATCH_MAX, "affine_batch: count %d not in 1..%d", count, FCD_AFFINE_BATCH_MAX);
+  FCD_REQUIRE(N > 0 && C > 0, "affine_batch: bad N / C");
+  AffineBatch b;
+  for (int i = 0; i < FCD_AFFINE_BATCH_MAX; ++i) {
+    const int j = i < count ? i : 0;
+    FCD_REQUIRE(s12[j] && (dgamma[j] || dbeta[j]), "affine_batch: null tensor");
+    b.s12[i] = s12[j]; b.dgamma[i] = dgamma[j]; b.dbeta[i] = dbeta[j];
+  }
+  hipLaunchKernelGGL(affine_batch_kernel, dim3(fcd_cdiv(C, 256), count), dim3(256), 0, fcd_stream(stream), b, N, C, accumulate);
+  return fcd_check_launch("affine_batch");
 }
 
 extern "C" size_t fcd_colsum_workspace_bytes(size_t rows, int C) {

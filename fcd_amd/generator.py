@@ -401,6 +401,7 @@ class _GeneratorFn(torch.autograd.Function):
                 amx_ok[i] = True
             return amx[i]
 
+        deferred = []          # (s12, dgamma sink, dbeta sink) of the norms whose affine gradients are summed at the end
         for li in range(len(plan) - 1, -1, -1):
             ly = plan[li]
             z, mean, rstd, use_running = saved[li]
@@ -415,11 +416,20 @@ class _GeneratorFn(torch.autograd.Function):
                 sg, sb = grad_sink(ly.norm.weight, needs[p0 + 1]), grad_sink(ly.norm.bias, needs[p0 + 2])
                 direct = want_aff and sg is not None and sb is not None
                 # the ReLU mask is recomputed from z (beta given): the forward output is not read again
-                dz, dgam, dbet = ops.instnorm_bwd(g, None, z, mean, rstd,
-                                                  ly.norm.weight.detach(), ly.act_slope, use_running,
-                                                  want_affine=want_aff, dgamma=sg if direct else None,
-                                                  dbeta=sb if direct else None, accumulate=direct,
-                                                  beta=ly.norm.bias.detach(), dz_amax=gmx[li] if h2 else None)
+                if direct and not final:
+                    # arena-backed gradients and nobody waiting for them before the pass ends: the sums over the
+                    # images of all norms go out in one launch per width after the layer loop (same bits)
+                    dz, s12 = ops.instnorm_bwd_deferred(g, z, mean, rstd, ly.norm.weight.detach(), ly.act_slope,
+                                                        use_running, ly.norm.bias.detach(),
+                                                        dz_amax=gmx[li] if h2 else None)
+                    deferred.append((s12, sg, sb))
+                    dgam = dbet = None
+                else:
+                    dz, dgam, dbet = ops.instnorm_bwd(g, None, z, mean, rstd,
+                                                      ly.norm.weight.detach(), ly.act_slope, use_running,
+                                                      want_affine=want_aff, dgamma=sg if direct else None,
+                                                      dbeta=sb if direct else None, accumulate=direct,
+                                                      beta=ly.norm.bias.detach(), dz_amax=gmx[li] if h2 else None)
                 dz_ok = h2
                 if not direct:
                     if needs[p0 + 1]:
@@ -479,5 +489,7 @@ class _GeneratorFn(torch.autograd.Function):
                 if h2 and d.w_amax:
                     d.a_amax = dz_amax().data_ptr()
                 g = ops.conv_gather(d, dz, wa, residual=res)
+        if deferred:
+            ops.instnorm_affine_batch(deferred, accumulate=True)
         ctx.acts = ctx.saved_layers = None
         return (None, gx, None) + tuple(grads)

@@ -480,6 +480,43 @@ def instnorm_bwd(gy, y, z, mean, rstd, gamma, act_slope: float, use_running: boo
     return dz, dgamma, dbeta
 
 
+AFFINE_BATCH_MAX = 32   # FCD_AFFINE_BATCH_MAX
+
+
+def instnorm_bwd_deferred(gy, z, mean, rstd, gamma, act_slope: float, use_running: bool, beta, dz_amax=None):
+    """The backward with the affine gradients left for :func:`instnorm_affine_batch`: returns ``(dz, s12)`` with
+    ``s12[n][c] = (sum g1, sum g1 * xhat)``."""
+    n, h, w, c = z.shape
+    lib = L.load()
+    dz = torch.empty_like(z)
+    s12 = torch.empty((n, c, 2), dtype=torch.float32, device=z.device)
+    wp, wn = _ws(lib.fcd_instnorm_workspace_bytes(n, h * w, c), z.device)
+    check(lib.fcd_instnorm_bwd_s12(ptr(gy), None, ptr(z), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(dz), ptr(s12), n,
+                                   h * w, c, act_slope, int(use_running), _amax_ptr(dz_amax), wp, wn, stream()),
+          "instnorm_bwd_s12")
+    return dz, s12
+
+
+def instnorm_affine_batch(items, accumulate: bool) -> None:
+    """``dgamma (+)= sum_n s12[n, :, 1]``, ``dbeta (+)= sum_n s12[n, :, 0]`` for a list of ``(s12, dgamma, dbeta)``:
+    one launch per group of equal (N, C) (at most AFFINE_BATCH_MAX norms each)."""
+    import ctypes
+    groups = {}
+    for it in items:
+        groups.setdefault(tuple(it[0].shape), []).append(it)
+    for (n, c, _), its in groups.items():
+        for i in range(0, len(its), AFFINE_BATCH_MAX):
+            part = its[i:i + AFFINE_BATCH_MAX]
+            for s12, dg, db in part:
+                for t in (dg, db):
+                    if t is not None and (t.numel() != c or t.dtype != torch.float32 or not t.is_contiguous()):
+                        raise RuntimeError("instnorm_affine_batch: a gradient is not a contiguous float32 tensor of C elements")
+            arr = ctypes.c_void_p * len(part)
+            cols = [arr(*[ptr(it[k]) for it in part]) for k in range(3)]
+            check(L.load().fcd_instnorm_affine_batch(cols[0], cols[1], cols[2], len(part), n, c, int(accumulate), stream()),
+                  "instnorm_affine_batch")
+
+
 # --------------------------------------------------------------------------- #
 # layout / Generator prologue + epilogue
 # --------------------------------------------------------------------------- #

@@ -256,6 +256,20 @@ int fcd_instnorm_bwd_amax(const float* gy, const float* y, const float* z, const
                           const float* gamma, const float* beta, float* dz, float* dgamma, float* dbeta,
                           int accumulate, int N, int HW, int C, float act_slope, int use_running,
                           float* dz_amax, void* workspace, size_t workspace_bytes, void* stream);
+/* The backward with the affine gradients deferred: dz (and max |dz|) as fcd_instnorm_bwd_amax, the per-image sums
+ * s12[n][c] = (sum g1, sum g1*xhat) into the caller's buffer (N*C*2 floats) and no dgamma / dbeta.
+ * fcd_instnorm_affine_batch then finishes dgamma[c] (+)= sum_n s12[n][c][1], dbeta[c] (+)= sum_n s12[n][c][0] for up to
+ * FCD_AFFINE_BATCH_MAX norms of equal N and C in ONE launch (HOST arrays of `count` device pointers; either gradient
+ * pointer of a norm may be NULL) -- the same sums in the same order as fcd_instnorm_bwd computes them, so the results
+ * are bit-identical; what goes is one small launch per norm from the backward chain's critical path
+ * (autograd of nn.InstanceNorm2d's weight / bias, fixed_point_gan.py:28,31,46,53,64). */
+#define FCD_AFFINE_BATCH_MAX 32
+int fcd_instnorm_bwd_s12(const float* gy, const float* y, const float* z, const float* mean, const float* rstd,
+                         const float* gamma, const float* beta, float* dz, float* s12, int N, int HW, int C,
+                         float act_slope, int use_running, float* dz_amax, void* workspace,
+                         size_t workspace_bytes, void* stream);
+int fcd_instnorm_affine_batch(const float* const* s12, float* const* dgamma, float* const* dbeta, int count,
+                              int N, int C, int accumulate, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Generator prologue / epilogue (fixed_point_gan.py:73-75 and :78-82).

@@ -332,3 +332,38 @@ def test_instnorm_backward_one_pass(dev, case, monkeypatch):
     acc_g, acc_b = torch.full_like(dg, 2.0), torch.full_like(db, -1.0)
     ops.instnorm_bwd(gd, None, zd, mean, rstd, gam, slope, use_running, beta=bet, dgamma=acc_g, dbeta=acc_b, accumulate=True)
     assert relerr(acc_g - 2.0, dg) <= 1e-5 and relerr(acc_b + 1.0, db) <= 1e-5
+
+
+@pytest.mark.parametrize("hw", [32, 20])
+def test_instnorm_backward_deferred_affine(dev, hw):
+    """fcd_instnorm_bwd_s12 + fcd_instnorm_affine_batch (one launch for several norms, grouped by (N, C)) == the affine
+    gradients fcd_instnorm_bwd accumulates itself, bit for bit, for the one-pass (32 x 32) and the three-kernel form."""
+    from fcd_amd import ops
+    torch.manual_seed(11)
+    items, want = [], []
+    for (n, c, slope) in [(8, 256, 0.0), (8, 256, 1.0), (8, 64, 0.2), (3, 64, 0.0), (8, 256, 0.0)]:
+        z = torch.randn(n, hw, hw, c, device=dev) * 2 + 0.4
+        gy = torch.randn(n, hw, hw, c, device=dev) * 1e-2
+        gamma, beta = torch.rand(c, device=dev) + 0.5, torch.randn(c, device=dev) * 0.2
+        mean, rstd, _ = ops.instnorm_stats(z)
+        g0, b0 = torch.randn(c, device=dev), torch.randn(c, device=dev)
+        rg, rb = g0.clone(), b0.clone()
+        am0, am1 = torch.zeros(ops.AMAX_SLOTS, device=dev), torch.zeros(ops.AMAX_SLOTS, device=dev)
+        dz0, _, _ = ops.instnorm_bwd(gy, None, z, mean, rstd, gamma, slope, False, beta=beta, dgamma=rg, dbeta=rb,
+                                     accumulate=True, dz_amax=am0)
+        dz1, s12 = ops.instnorm_bwd_deferred(gy, z, mean, rstd, gamma, slope, False, beta, dz_amax=am1)
+        assert torch.equal(dz0, dz1) and torch.equal(am0, am1)
+        dg, db = g0.clone(), b0.clone()
+        items.append((s12, dg, db))
+        want.append((rg, rb))
+    items[-1] = (items[-1][0], items[-1][1], None)        # a norm whose bias gradient is not wanted
+    ops.instnorm_affine_batch(items, accumulate=True)
+    for (s12, dg, db), (rg, rb) in zip(items, want):
+        assert torch.equal(dg, rg)
+        assert db is None or torch.equal(db, rb)
+    # overwrite instead of accumulate
+    dg, db = torch.full((256,), 7.0, device=dev), torch.full((256,), 7.0, device=dev)
+    ops.instnorm_affine_batch([(items[0][0], dg, db)], accumulate=False)
+    assert torch.equal(dg, items[0][0][:, :, 1].double().sum(0).float()) or relerr(dg, items[0][0][:, :, 1].double().sum(0)) <= 1e-6
+    with pytest.raises(RuntimeError):
+        ops.instnorm_affine_batch([(items[0][0], None, None)], accumulate=True)
