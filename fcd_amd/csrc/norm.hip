@@ -709,7 +709,7 @@ int fcd_finalize_apply(const double* partial, const float* z, float* mean, float
                        int C, int chunks, float eps, const float* gamma, const float* beta, const float* residual, float* y,
                        float act_slope, float* y_amax, hipStream_t st) {
   if (HW == IN1P_HW && C % 32 == 0 && chunks <= IN1F_MAX_CHUNKS && act_slope <= 1.f && (long)N * (C / 32) >= 64 &&
-      !getenv("FCD_NO_IN1F")) {
+      N <= 65535 && !getenv("FCD_NO_IN1F")) {
     hipLaunchKernelGGL(in_fwd_onepass_kernel, dim3(C / 32, N), dim3(64 * IN1P_WAVES), 0, st, z, partial, chunks, eps, gamma, beta,
                        residual, y, mean, rstd, var_unbiased, C, act_slope, (unsigned*)y_amax);
     return fcd_check_launch("instnorm_fwd/onepass");
@@ -947,7 +947,7 @@ int instnorm_bwd_impl(const float* gy, const float* y, const float* z, const flo
   double* partial = (double*)workspace;
   float* s12 = s12_out ? s12_out : (float*)((char*)workspace + pb);
   if (HW == IN1P_HW && C % 32 == 0 && act_slope <= 1.f && (beta || act_slope == 1.f) && (long)N * (C / 32) >= 64 &&
-      !getenv("FCD_NO_IN1P")) {
+      N <= 65535 && !getenv("FCD_NO_IN1P")) {
     // one pass: (image, 32 channels) per workgroup, both operand slices in registers
     hipLaunchKernelGGL(in_bwd_onepass_kernel, dim3(C / 32, N), dim3(64 * IN1P_WAVES), 0, st, gy, z, mean, rstd, gamma, beta, dz, s12, C,
                        act_slope, use_running, (unsigned*)dz_amax);
