@@ -89,6 +89,7 @@ PROTOTYPES = {
     "fcd_instnorm_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P]),
     "fcd_instnorm_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P, _Z, _P]),
     "fcd_absmax": (_I, [_P, _Z, _P, _P]),
+    "fcd_absmax_batch": (_I, [_P, _P, _I, _P, _P]),
     "fcd_instnorm_apply_amax": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P]),
     "fcd_instnorm_bwd_amax": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P, _P, _Z, _P]),
     "fcd_instnorm_bwd_s12": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _P, _P, _Z, _P]),

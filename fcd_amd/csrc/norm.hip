@@ -886,6 +886,47 @@ extern "C" int fcd_instnorm_update_running(float* running_mean, float* running_v
   return fcd_check_launch("update_running");
 }
 
+namespace {
+// max |x| of up to FCD_ABSMAX_BATCH_MAX tensors in one launch (blockIdx.y = tensor), OVERWRITING the tensor's row of
+// FCD_AMAX_SLOTS partial maxima: block b stores slot b and clears slots b + 256, b + 512, b + 768 (no zeroing pass)
+struct AbsmaxBatch {
+  const float* x[FCD_ABSMAX_BATCH_MAX];
+  size_t n4[FCD_ABSMAX_BATCH_MAX];
+};
+__global__ __launch_bounds__(256) void absmax_batch_kernel(const AbsmaxBatch bt, float* __restrict__ rows) {
+  __shared__ float wave_max[4];
+  const float* __restrict__ x = bt.x[blockIdx.y];
+  const size_t n4 = bt.n4[blockIdx.y];
+  float m = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    m = fmaxf(fmaxf(fmaxf(m, fabsf(v.x)), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = m;
+  __syncthreads();
+  float* row = rows + (size_t)blockIdx.y * FCD_AMAX_SLOTS;
+  if (threadIdx.x == 0) row[blockIdx.x] = fmaxf(fmaxf(wave_max[0], wave_max[1]), fmaxf(wave_max[2], wave_max[3]));
+  else if (threadIdx.x < FCD_AMAX_SLOTS / 256) row[blockIdx.x + 256 * threadIdx.x] = 0.f;
+}
+}  // namespace
+
+extern "C" int fcd_absmax_batch(const float* const* x, const size_t* n, int count, float* amax_rows, void* stream) {
+  FCD_REQUIRE(x && n && amax_rows, "absmax_batch: null array");
+  FCD_REQUIRE(count >= 1 && count <= FCD_ABSMAX_BATCH_MAX, "absmax_batch: count %d not in 1..%d", count, FCD_ABSMAX_BATCH_MAX);
+  AbsmaxBatch b;
+  for (int i = 0; i < FCD_ABSMAX_BATCH_MAX; ++i) {
+    const int j = i < count ? i : 0;
+    FCD_REQUIRE(x[j] && n[j] % 4 == 0 && ((uintptr_t)x[j] % 16) == 0,
+                "absmax_batch: null tensor, or a length / address that is not a multiple of 4 floats");
+    b.x[i] = x[j]; b.n4[i] = n[j] / 4;
+  }
+  static_assert(FCD_AMAX_SLOTS == 1024, "absmax_batch_kernel clears slots in four strides of 256");
+  hipLaunchKernelGGL(absmax_batch_kernel, dim3(256, count), dim3(256), 0, fcd_stream(stream), b, amax_rows);
+  return fcd_check_launch("absmax_batch");
+}
+
 extern "C" int fcd_absmax(const float* x, size_t n, float* amax, void* stream) {
   FCD_REQUIRE(x && amax && n % 4 == 0 && ((uintptr_t)x % 16) == 0, "absmax: null tensor, or a length / address that is not a multiple of 4 floats");
   const int blocks = (int)std::min<size_t>((n / 4 + 255) / 256, FCD_AMAX_SLOTS);

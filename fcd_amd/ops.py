@@ -454,6 +454,27 @@ def absmax(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     return out
 
 
+ABSMAX_BATCH_MAX = 32   # FCD_ABSMAX_BATCH_MAX
+
+
+def absmax_batch(tensors, out: torch.Tensor) -> torch.Tensor:
+    """Row ``i`` of ``out`` (``len(tensors)`` x AMAX_SLOTS, float32, contiguous) := the partial maxima of ``|tensors[i]|``;
+    one launch per ABSMAX_BATCH_MAX tensors, rows are overwritten (no zeroing needed)."""
+    import ctypes
+    if out.dtype != torch.float32 or not out.is_cuda or not out.is_contiguous() or tuple(out.shape) != (len(tensors), AMAX_SLOTS):
+        raise ValueError(f"absmax_batch: out must be a contiguous float32 device tensor of shape ({len(tensors)}, {AMAX_SLOTS})")
+    for t in tensors:
+        L.require_gpu_tensor(t, "tensor")
+        if t.numel() % 4 or t.data_ptr() % 16:
+            raise RuntimeError("absmax_batch: a tensor's length / address is not a multiple of 4 floats")
+    for i in range(0, len(tensors), ABSMAX_BATCH_MAX):
+        part = tensors[i:i + ABSMAX_BATCH_MAX]
+        xs = (ctypes.c_void_p * len(part))(*[t.data_ptr() for t in part])
+        ns = (ctypes.c_size_t * len(part))(*[t.numel() for t in part])
+        check(L.load().fcd_absmax_batch(xs, ns, len(part), out[i].data_ptr(), stream()), "absmax_batch")
+    return out
+
+
 def instnorm_apply(z, mean, rstd, gamma, beta, act_slope: float, residual=None, out=None, amax=None):
     """``amax`` (a zeroed AMAX_SLOTS-element device tensor): also receives ``max |out|`` (PREC_F16X2 operand scaling)."""
     n, h, w, c = z.shape

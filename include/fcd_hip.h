@@ -249,6 +249,11 @@ int fcd_instnorm_bwd(const float* gy, const float* y, const float* z, const floa
  * producing block, no atomics; the value is the maximum of the slots): slot = max(slot, ...), so the caller
  * zeroes the array first; fcd_absmax does the same for any tensor (n floats, a multiple of 4, 16-byte aligned). */
 int fcd_absmax(const float* x, size_t n, float* amax, void* stream);
+/* max |.| of up to FCD_ABSMAX_BATCH_MAX tensors in one launch (what a network's weights need once per optimizer step):
+ * x and n are HOST arrays of `count` device pointers / lengths in floats; row i of amax_rows (count x FCD_AMAX_SLOTS
+ * floats) is OVERWRITTEN with tensor i's partial maxima -- no zeroing beforehand, unlike fcd_absmax. */
+#define FCD_ABSMAX_BATCH_MAX 32
+int fcd_absmax_batch(const float* const* x, const size_t* n, int count, float* amax_rows, void* stream);
 int fcd_instnorm_apply_amax(const float* z, const float* mean, const float* rstd, const float* gamma,
                             const float* beta, const float* residual, float* y, int N, int HW, int C,
                             float act_slope, float* y_amax, void* stream);

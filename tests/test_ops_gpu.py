@@ -367,3 +367,23 @@ def test_instnorm_backward_deferred_affine(dev, hw):
     assert torch.equal(dg, items[0][0][:, :, 1].double().sum(0).float()) or relerr(dg, items[0][0][:, :, 1].double().sum(0)) <= 1e-6
     with pytest.raises(RuntimeError):
         ops.instnorm_affine_batch([(items[0][0], None, None)], accumulate=True)
+
+
+def test_absmax_batch(dev):
+    """fcd_absmax_batch: rows overwritten (stale contents do not leak), equal to per-tensor maxima; more tensors than one
+    launch takes; refusal of unaligned lengths."""
+    from fcd_amd import ops
+    torch.manual_seed(12)
+    ts = [torch.randn(n, device=dev) * (i + 1) for i, n in enumerate([4, 1024, 37632, 589824, 2 ** 21 + 8] + [64] * 31)]
+    out = torch.full((len(ts), ops.AMAX_SLOTS), 1e9, device=dev)
+    ops.absmax_batch(ts, out)
+    for i, t in enumerate(ts):
+        assert float(out[i].max()) == float(t.abs().max()), i
+        assert float(out[i].min()) >= 0.0
+    ts[1].zero_()
+    ops.absmax_batch(ts, out)
+    assert float(out[1].max()) == 0.0
+    with pytest.raises(RuntimeError):
+        ops.absmax_batch([torch.randn(6, device=dev)], torch.empty((1, ops.AMAX_SLOTS), device=dev))
+    with pytest.raises(ValueError):
+        ops.absmax_batch(ts, torch.empty((2, ops.AMAX_SLOTS), device=dev))
