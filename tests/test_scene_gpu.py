@@ -277,3 +277,55 @@ def test_eval_difference_map_full_width(dev, mode):
     diff32, _ = s.difference_and_mask(xb, 0.02)
     assert float((diff32[:2] - diff).abs().max()) <= 2e-6 * float(ref.abs().max())
     assert float((diff32[30:32] - diff).abs().max()) <= 2e-6 * float(ref.abs().max())
+
+
+def test_weight_maxima_pool_follows_the_weights(dev):
+    """The generator's weight maxima come from one batched launch per set of parameter versions (WeightMaxima): after an
+    in-place update of one weight, of all weights, after load_state_dict and for a deep copy of the network the fp32x2
+    forward equals the forward of a freshly built network with the same weights, bit for bit."""
+    import copy
+    from fcd_amd import FCDSolver
+    gs = O.synth_generator_state()
+    (x, _, _, _, _), _ = O.synth_batch(2, 128, 10, seed=5)
+    xd = x.to(dev)
+    c = torch.zeros(2, 1, device=dev)
+
+    def fresh(state):
+        s2 = FCDSolver(None, precision="fp32x2")
+        s2.G.load_state_dict(state)
+        s2.to(dev)
+        with torch.no_grad():
+            return s2.G(xd, c)
+
+    s = FCDSolver(None, precision="fp32x2")
+    s.G.load_state_dict(gs)
+    s.to(dev)
+    pool = s.G._wmax
+    with torch.no_grad():
+        y0 = s.G(xd, c)
+        assert pool.keys is not None and torch.equal(y0, fresh(gs))
+        for r, cv in zip(pool.buf, pool.convs):
+            assert float(r.max()) == float(cv.weight.abs().max())
+        # one weight changes in place (its version moves): the pool is refreshed at the next forward
+        s.G.main[9].main[0].weight.mul_(1.5)
+        y1 = s.G(xd, c)
+        st = {k: v.detach().cpu().clone() for k, v in s.G.state_dict().items()}
+        assert not torch.equal(y1, y0) and torch.equal(y1, fresh(st))
+        # a weight changes between the refresh and its use: that convolution falls back to its own maximum
+        cv = pool.convs[3]
+        cv.weight.mul_(0.5)
+        assert pool.row(cv, cv._key()) is None
+        assert float(cv.weight_amax().max()) == float(cv.weight.abs().max())
+        # every weight, then a state dict
+        for p in s.G.parameters():
+            p.mul_(1.01)
+        st = {k: v.detach().cpu().clone() for k, v in s.G.state_dict().items()}
+        assert torch.equal(s.G(xd, c), fresh(st))
+        s.G.load_state_dict(gs)
+        assert torch.equal(s.G(xd, c), y0)
+        g2 = copy.deepcopy(s.G)
+        assert torch.equal(g2(xd, c), y0)
+        g2.main[0].weight.mul_(2.0)
+        st = {k: v.detach().cpu().clone() for k, v in g2.state_dict().items()}
+        assert torch.equal(g2(xd, c), fresh(st))
+        assert torch.equal(s.G(xd, c), y0)
