@@ -75,6 +75,8 @@ PROTOTYPES = {
     "fcd_conv_weight_format": (_I, [C.POINTER(ConvDesc)]),
     "fcd_pack_weight_fwd_h2": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "fcd_pack_weight_adj_h2": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "fcd_pack_weight_fwd_h2_batch": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "fcd_pack_weight_adj_h2_batch": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "fcd_pack_weight_fwd_x3": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "fcd_pack_weight_adj_x3": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "fcd_head_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),

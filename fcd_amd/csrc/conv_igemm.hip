@@ -2895,8 +2895,8 @@ __device__ __forceinline__ void store_split2(unsigned short* __restrict__ out, l
   out[idx] = __builtin_bit_cast(unsigned short, h);
   out[plane_stride + idx] = __builtin_bit_cast(unsigned short, l);
 }
-__global__ __launch_bounds__(256) void pack_fwd_h2_kernel(const float* __restrict__ w, unsigned short* __restrict__ out,
-                                                          int O, int I, int IP, int taps, const float* __restrict__ amax) {
+__device__ __forceinline__ void pack_fwd_h2_body(const float* __restrict__ w, unsigned short* __restrict__ out,
+                                                 int O, int I, int IP, int taps, const float* __restrict__ amax) {
   const float sc = pow2_scale(amax);
   const long total = (long)O * taps * IP;
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
@@ -2906,10 +2906,14 @@ __global__ __launch_bounds__(256) void pack_fwd_h2_kernel(const float* __restric
     store_split2(out, total, idx, i < I ? sc * w[((long)o * I + i) * taps + tap] : 0.f);
   }
 }
+__global__ __launch_bounds__(256) void pack_fwd_h2_kernel(const float* __restrict__ w, unsigned short* __restrict__ out,
+                                                          int O, int I, int IP, int taps, const float* __restrict__ amax) {
+  pack_fwd_h2_body(w, out, O, I, IP, taps, amax);
+}
 // out[phase][plane][i][th][tw][o], element order of pack_adj_x3_kernel
-__global__ __launch_bounds__(256) void pack_adj_h2_kernel(const float* __restrict__ w, unsigned short* __restrict__ out,
-                                                          int O, int OP, int I, int KH, int KW, int stride,
-                                                          const float* __restrict__ amax) {
+__device__ __forceinline__ void pack_adj_h2_body(const float* __restrict__ w, unsigned short* __restrict__ out,
+                                                 int O, int OP, int I, int KH, int KW, int stride,
+                                                 const float* __restrict__ amax) {
   const float sc = pow2_scale(amax);
   const int TH = stride == 1 ? KH : 2, TW = stride == 1 ? KW : 2;
   const int nph = stride == 1 ? 1 : 4;
@@ -2933,6 +2937,24 @@ __global__ __launch_bounds__(256) void pack_adj_h2_kernel(const float* __restric
     store_split2(out + (long)ph * 2 * per_phase, per_phase, idx - (long)ph * per_phase,
                  o < O ? sc * w[(((long)o * I + i) * KH + kh) * KW + kw] : 0.f);
   }
+}
+__global__ __launch_bounds__(256) void pack_adj_h2_kernel(const float* __restrict__ w, unsigned short* __restrict__ out,
+                                                          int O, int OP, int I, int KH, int KW, int stride,
+                                                          const float* __restrict__ amax) {
+  pack_adj_h2_body(w, out, O, OP, I, KH, KW, stride, amax);
+}
+// The same packs for up to FCD_PACK_BATCH_MAX weights of one shape in one launch (blockIdx.y = weight): a network's
+// twelve residual-block convolutions are re-packed after every optimizer step, 24 launches of 6 - 9 us each
+struct PackBatch {
+  const float* w[FCD_PACK_BATCH_MAX];
+  unsigned short* out[FCD_PACK_BATCH_MAX];
+  const float* amax[FCD_PACK_BATCH_MAX];
+};
+__global__ __launch_bounds__(256) void pack_fwd_h2_batch_kernel(const PackBatch b, int O, int I, int IP, int taps) {
+  pack_fwd_h2_body(b.w[blockIdx.y], b.out[blockIdx.y], O, I, IP, taps, b.amax[blockIdx.y]);
+}
+__global__ __launch_bounds__(256) void pack_adj_h2_batch_kernel(const PackBatch b, int O, int OP, int I, int KH, int KW, int stride) {
+  pack_adj_h2_body(b.w[blockIdx.y], b.out[blockIdx.y], O, OP, I, KH, KW, stride, b.amax[blockIdx.y]);
 }
 
 // Demangled symbol (as rocprofv3 prints it, without namespace and argument list) of the last convolution /
@@ -3786,6 +3808,45 @@ extern "C" int fcd_pack_weight_adj_h2(const float* w, void* packed, const float*
   hipLaunchKernelGGL(pack_adj_h2_kernel, dim3(blocks), dim3(256), 0, fcd_stream(stream), w, (unsigned short*)packed, O, OP, I,
                      KH, KW, stride, w_amax);
   return fcd_check_launch("pack_weight_adj_h2");
+}
+
+namespace {
+int fill_pack_batch(PackBatch& b, const float* const* w, void* const* packed, const float* const* w_amax, int count) {
+  FCD_REQUIRE(w && packed && w_amax, "pack_weight_h2_batch: null array");
+  FCD_REQUIRE(count >= 1 && count <= FCD_PACK_BATCH_MAX, "pack_weight_h2_batch: count %d not in 1..%d", count, FCD_PACK_BATCH_MAX);
+  for (int i = 0; i < FCD_PACK_BATCH_MAX; ++i) {
+    const int j = i < count ? i : 0;
+    FCD_REQUIRE(w[j] && packed[j] && w_amax[j], "pack_weight_h2_batch: null tensor");
+    b.w[i] = w[j]; b.out[i] = (unsigned short*)packed[j]; b.amax[i] = w_amax[j];
+  }
+  return FCD_OK;
+}
+}  // namespace
+
+extern "C" int fcd_pack_weight_fwd_h2_batch(const float* const* w, void* const* packed, const float* const* w_amax, int count,
+                                            int O, int I, int IP, int KH, int KW, void* stream) {
+  FCD_REQUIRE(O > 0 && I > 0 && IP >= I && IP % 4 == 0 && KH > 0 && KW > 0, "pack_weight_fwd_h2_batch: bad arguments");
+  PackBatch b;
+  int rc = fill_pack_batch(b, w, packed, w_amax, count);
+  if (rc) return rc;
+  const long total = (long)O * KH * KW * IP;
+  const int blocks = (int)std::min<long>(fcd_cdiv(total, 256), 4096);
+  hipLaunchKernelGGL(pack_fwd_h2_batch_kernel, dim3(blocks, count), dim3(256), 0, fcd_stream(stream), b, O, I, IP, KH * KW);
+  return fcd_check_launch("pack_weight_fwd_h2_batch");
+}
+
+extern "C" int fcd_pack_weight_adj_h2_batch(const float* const* w, void* const* packed, const float* const* w_amax, int count,
+                                            int O, int OP, int I, int KH, int KW, int stride, void* stream) {
+  FCD_REQUIRE(O > 0 && I > 0 && OP >= O && OP % 4 == 0 && KH > 0 && KW > 0, "pack_weight_adj_h2_batch: bad arguments");
+  FCD_REQUIRE((stride == 1) || (stride == 2 && KH == 4 && KW == 4), "pack_weight_adj_h2_batch: unsupported stride/kernel");
+  PackBatch b;
+  int rc = fill_pack_batch(b, w, packed, w_amax, count);
+  if (rc) return rc;
+  const int TH = stride == 1 ? KH : 2, TW = stride == 1 ? KW : 2, nph = stride == 1 ? 1 : 4;
+  const long total = (long)nph * I * TH * TW * OP;
+  const int blocks = (int)std::min<long>(fcd_cdiv(total, 256), 4096);
+  hipLaunchKernelGGL(pack_adj_h2_batch_kernel, dim3(blocks, count), dim3(256), 0, fcd_stream(stream), b, O, OP, I, KH, KW, stride);
+  return fcd_check_launch("pack_weight_adj_h2_batch");
 }
 
 extern "C" int fcd_pack_weight_fwd_x3(const float* w, void* packed, int O, int I, int IP, int KH, int KW, void* stream) {

@@ -71,6 +71,20 @@ class WeightMaxima:
             self.rows = {i: r for r, (i, _) in enumerate(ws)}
             if ws:
                 ops.absmax_batch([w for _, w in ws], self.buf[:len(ws)])
+            # the two-fp16-plane operands the layers asked for last time ("fwdh" / "adjh"), one launch per shape
+            groups = {}
+            for i, w in ws:
+                c = self.convs[i]
+                for kind, geom in getattr(c, "_h2_wanted", {}).items():
+                    hit = c._packed.get(kind)
+                    if hit is None or hit[0] != keys[i]:
+                        gk = (kind, tuple(w.shape), geom.O, geom.I, geom.k, geom.s, geom.p, geom.OP, geom.IP)
+                        groups.setdefault(gk, []).append((i, w, geom))
+            for (kind, *_), items in groups.items():
+                rows = [self.buf[self.rows[i]] for i, _, _ in items]
+                outs = ops.pack_weight_h2_batch(kind[:3], [w for _, w, _ in items], items[0][2], rows)
+                for (i, _, _), t, wa in zip(items, outs, rows):
+                    self.convs[i]._packed[kind] = (keys[i], (t, wa))
         self.keys = keys
 
     def row(self, conv, key):
@@ -139,6 +153,10 @@ class ConvParams(nn.Module):
         hit = self._packed.get(kind)
         if hit is not None and hit[0] == key:
             return hit[1]
+        if kind.endswith("h"):
+            # remembered for WeightMaxima.refresh: the next set of parameter versions is packed for all layers of this
+            # shape in one launch
+            self.__dict__.setdefault("_h2_wanted", {})[kind] = geom
         with torch.no_grad():
             wd = w.detach().contiguous()
             if kind.endswith("h"):

@@ -335,6 +335,38 @@ def pack_weight_adj_h2(w: torch.Tensor, g: ConvGeom, w_amax: torch.Tensor) -> to
     return out
 
 
+PACK_BATCH_MAX = 16   # FCD_PACK_BATCH_MAX
+
+
+def pack_weight_h2_batch(kind: str, ws, g: ConvGeom, w_amaxes):
+    """``pack_weight_fwd_h2`` (kind "fwd") / ``pack_weight_adj_h2`` ("adj") of several weights of one geometry in one
+    launch per PACK_BATCH_MAX weights; returns the list of packed tensors."""
+    import ctypes
+    lib = L.load()
+    outs = []
+    for w in ws:
+        L.require_gpu_tensor(w, "weight")
+        if tuple(w.shape) != tuple(ws[0].shape):
+            raise RuntimeError("pack_weight_h2_batch: weights of different shapes")
+        if kind == "fwd":
+            outs.append(torch.empty((2, g.O, g.k, g.k, g.IP), dtype=torch.float16, device=w.device))
+        else:
+            t = g.adj_taps()
+            outs.append(torch.empty((g.adj_phases(), 2, g.I, t, t, g.OP), dtype=torch.float16, device=w.device))
+    for i in range(0, len(ws), PACK_BATCH_MAX):
+        n = len(ws[i:i + PACK_BATCH_MAX])
+        arr = ctypes.c_void_p * n
+        wp = arr(*[ptr(w) for w in ws[i:i + n]])
+        op = arr(*[ptr(o) for o in outs[i:i + n]])
+        ap = arr(*[_amax_ptr(a) for a in w_amaxes[i:i + n]])
+        if kind == "fwd":
+            check(lib.fcd_pack_weight_fwd_h2_batch(wp, op, ap, n, g.O, g.I, g.IP, g.k, g.k, stream()), "pack_weight_fwd_h2_batch")
+        else:
+            check(lib.fcd_pack_weight_adj_h2_batch(wp, op, ap, n, g.O, g.OP, g.I, g.k, g.k, g.s, stream()),
+                  "pack_weight_adj_h2_batch")
+    return outs
+
+
 def pack_weight_fwd_x3(w: torch.Tensor, g: ConvGeom) -> torch.Tensor:
     L.require_gpu_tensor(w, "weight")
     out = torch.empty((3, g.O, g.k, g.k, g.IP), dtype=torch.bfloat16, device=w.device)

@@ -170,6 +170,14 @@ int fcd_pack_weight_fwd_h2(const float* w, void* packed, const float* w_amax, in
                            void* stream);
 int fcd_pack_weight_adj_h2(const float* w, void* packed, const float* w_amax, int O, int OP, int I, int KH, int KW,
                            int stride, void* stream);
+/* The same two packs for up to FCD_PACK_BATCH_MAX weights of ONE shape in one launch (HOST arrays of `count` device
+ * pointers): what a network does after every optimizer step for its equal-shaped layers (the generator's twelve
+ * residual-block convolutions).  Same bytes as `count` single calls. */
+#define FCD_PACK_BATCH_MAX 16
+int fcd_pack_weight_fwd_h2_batch(const float* const* w, void* const* packed, const float* const* w_amax, int count,
+                                 int O, int I, int IP, int KH, int KW, void* stream);
+int fcd_pack_weight_adj_h2_batch(const float* const* w, void* const* packed, const float* const* w_amax, int count,
+                                 int O, int OP, int I, int KH, int KW, int stride, void* stream);
 int fcd_pack_weight_fwd_x3(const float* w, void* packed, int O, int I, int IP, int KH, int KW,
                            void* stream);
 int fcd_pack_weight_adj_x3(const float* w, void* packed, int O, int OP, int I, int KH, int KW,

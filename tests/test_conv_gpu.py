@@ -829,3 +829,22 @@ def test_conv_out_amax(dev, case):
     ops.set_out_amax(d, am2)
     ops.conv_gather(d, x, wp, bias=bias, residual=res)
     assert float(am2.max()) == 1e9
+
+
+@pytest.mark.parametrize("geom", [(256, 256, 3, 1, 1), (128, 64, 4, 2, 1), (40, 24, 3, 1, 1)])
+def test_pack_weight_h2_batch(dev, geom):
+    """fcd_pack_weight_{fwd,adj}_h2_batch == the single packs, byte for byte, for more weights than one launch takes."""
+    from fcd_amd import ops
+    O, I, k, s, p = geom
+    g = ops.ConvGeom(O, I, k, s, p)
+    torch.manual_seed(9)
+    ws = [torch.randn(O, I, k, k, device=dev) * (0.01 * (j + 1)) for j in range(19)]
+    amax = torch.empty((len(ws), ops.AMAX_SLOTS), device=dev)
+    ops.absmax_batch(ws, amax)
+    for kind, single in (("fwd", ops.pack_weight_fwd_h2), ("adj", ops.pack_weight_adj_h2)):
+        outs = ops.pack_weight_h2_batch(kind, ws, g, [amax[j] for j in range(len(ws))])
+        for j, w in enumerate(ws):
+            ref = single(w, g, amax[j])
+            assert outs[j].shape == ref.shape and torch.equal(outs[j].view(torch.int16), ref.view(torch.int16)), (kind, j)
+    with pytest.raises(RuntimeError):
+        ops.pack_weight_h2_batch("fwd", [ws[0], torch.randn(O, I + 4, k, k, device=dev)], g, [amax[0], amax[1]])
