@@ -46,7 +46,9 @@ class WeightMaxima:
     (``fcd_absmax_batch``) instead of a zero-fill and a launch per layer: 17 + 17 small launches per generator step.
     ``refresh()`` at the start of a forward pass; ``row()`` answers only for the versions it was refreshed with (a
     convolution whose weight changed since, or whose weight the batched kernel does not take, falls back to its own
-    ``absmax``)."""
+    ``absmax``).  ``refresh()`` also re-packs, one launch per shape and direction (``fcd_pack_weight_*_h2_batch``), the
+    two-fp16-plane operands the layers asked for under the previous versions (``ConvParams._h2_wanted``); a layer
+    that asks for something else packs it itself, as before."""
 
     def __init__(self, convs):
         self.convs = list(convs)
