@@ -500,6 +500,9 @@ __global__ __launch_bounds__(64 * IN1P_WAVES) void in_bwd_onepass_kernel(const f
 // results are bit-identical to the two-kernel form), then normalises from registers.  Saves the finalize launch between
 // the convolution and the apply (4.8 us on the critical path, 39 times a step).  (Leaky)ReLU slopes only.
 constexpr int IN1F_MAX_CHUNKS = 32;
+// PARTS: workgroups per (image, 32 channels), each with 1024 / PARTS pixels (blockIdx.z; the statistics are finished by
+// every part, written by part 0) -- two when one per slice would leave CUs idle (16-sample launches: 128 slices)
+template <int PARTS>
 __global__ __launch_bounds__(64 * IN1P_WAVES) void in_fwd_onepass_kernel(const float* __restrict__ z, const double* __restrict__ partial,
                                                              int chunks, float eps, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, const float* __restrict__ res,
@@ -516,14 +519,15 @@ __global__ __launch_bounds__(64 * IN1P_WAVES) void in_fwd_onepass_kernel(const f
   __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc((char*)z + img, (short)0, img_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((char*)(res ? res : z) + img, (short)0, img_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((char*)y + img, (short)0, img_bytes, 0x00020000);
-  const int voff = (pl * C + c0) * 4, jstep = 128 * C * 4;
+  constexpr int NJ = IN1P_J / PARTS;
+  const int jstep = 128 * C * 4, voff = (pl * C + c0) * 4 + (int)blockIdx.z * NJ * jstep;
   typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-  float4 zz[IN1P_J], rv[IN1P_J];
+  float4 zz[NJ], rv[NJ];
 #pragma unroll
-  for (int j = 0; j < IN1P_J; ++j) zz[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rz, voff, j * jstep, 0));
+  for (int j = 0; j < NJ; ++j) zz[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rz, voff, j * jstep, 0));
   if (res) {
 #pragma unroll
-    for (int j = 0; j < IN1P_J; ++j) rv[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rr, voff, j * jstep, 0));
+    for (int j = 0; j < NJ; ++j) rv[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rr, voff, j * jstep, 0));
   }
   {
     const int c = tid & 31, k = tid >> 5;
@@ -551,9 +555,11 @@ __global__ __launch_bounds__(64 * IN1P_WAVES) void in_fwd_onepass_kernel(const f
     if (var < 0.0) var = 0.0;
     const float mf = (float)m, rf = (float)(1.0 / sqrt(var + (double)eps));
     const long idx = (long)n * C + blockIdx.x * 32 + tid;
-    mean[idx] = mf;
-    rstd[idx] = rf;
-    if (varu) varu[idx] = (float)(var * ((double)IN1P_HW / (double)(IN1P_HW - 1)));
+    if (blockIdx.z == 0) {
+      mean[idx] = mf;
+      rstd[idx] = rf;
+      if (varu) varu[idx] = (float)(var * ((double)IN1P_HW / (double)(IN1P_HW - 1)));
+    }
     st[tid][0] = mf;
     st[tid][1] = rf;
   }
@@ -568,7 +574,7 @@ __global__ __launch_bounds__(64 * IN1P_WAVES) void in_fwd_onepass_kernel(const f
   }
   float am = 0.f;
 #pragma unroll
-  for (int j = 0; j < IN1P_J; ++j) {
+  for (int j = 0; j < NJ; ++j) {
     const float zv[4] = {zz[j].x, zz[j].y, zz[j].z, zz[j].w};
     float o[4];
 #pragma unroll
@@ -590,8 +596,8 @@ __global__ __launch_bounds__(64 * IN1P_WAVES) void in_fwd_onepass_kernel(const f
       float m = 0.f;
 #pragma unroll
       for (int k = 0; k < IN1P_WAVES; ++k) m = fmaxf(m, wmax[k]);
-      const unsigned b = __float_as_uint(m), blocks = gridDim.x * gridDim.y;
-      unsigned* slot = amax + ((blockIdx.y * gridDim.x + blockIdx.x) & (FCD_AMAX_SLOTS - 1));
+      const unsigned b = __float_as_uint(m), blocks = gridDim.x * gridDim.y * gridDim.z;
+      unsigned* slot = amax + (((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) & (FCD_AMAX_SLOTS - 1));
       if (blocks <= FCD_AMAX_SLOTS) {
         if (b > *slot) *slot = b;
       } else if (b > __builtin_nontemporal_load(slot)) {
@@ -710,8 +716,12 @@ int fcd_finalize_apply(const double* partial, const float* z, float* mean, float
                        float act_slope, float* y_amax, hipStream_t st) {
   if (HW == IN1P_HW && C % 32 == 0 && chunks <= IN1F_MAX_CHUNKS && act_slope <= 1.f && (long)N * (C / 32) >= 64 &&
       N <= 65535 && !getenv("FCD_NO_IN1F")) {
-    hipLaunchKernelGGL(in_fwd_onepass_kernel, dim3(C / 32, N), dim3(64 * IN1P_WAVES), 0, st, z, partial, chunks, eps, gamma, beta,
-                       residual, y, mean, rstd, var_unbiased, C, act_slope, (unsigned*)y_amax);
+    if ((long)N * (C / 32) < 256)
+      hipLaunchKernelGGL(in_fwd_onepass_kernel<2>, dim3(C / 32, N, 2), dim3(64 * IN1P_WAVES), 0, st, z, partial, chunks, eps, gamma,
+                         beta, residual, y, mean, rstd, var_unbiased, C, act_slope, (unsigned*)y_amax);
+    else
+      hipLaunchKernelGGL(in_fwd_onepass_kernel<1>, dim3(C / 32, N), dim3(64 * IN1P_WAVES), 0, st, z, partial, chunks, eps, gamma,
+                         beta, residual, y, mean, rstd, var_unbiased, C, act_slope, (unsigned*)y_amax);
     return fcd_check_launch("instnorm_fwd/onepass");
   }
   int rc = fcd_finalize_stats(partial, mean, rstd, var_unbiased, N, HW, C, chunks, eps, st);
