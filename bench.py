@@ -11,6 +11,7 @@ MFMA-bound) timed live with HIP events on the launch stream, and `cpu_baseline`:
 oracle (a port of the reference's step) timed on this box's host cores on a bounded sample.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -62,6 +63,83 @@ def engine_clock_mhz(dev):
     except Exception:
         pass
     return None
+
+
+def _sysfs_device_dir(dev):
+    import glob
+    p = torch.cuda.get_device_properties(dev)
+    bdf = "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+    for d in glob.glob("/sys/class/drm/card*/device"):
+        if os.path.basename(os.path.realpath(d)) == bdf:
+            return d
+    return None
+
+
+class SysfsSampler:
+    """Engine clock (pp_dpm_sclk, the level marked '*') and socket power (hwmon power1_average / power1_input,
+    microwatts) of `dev`, read every `period` seconds by a side thread while the timed region runs.  The reads
+    block in the kernel (GIL released); nothing is sampled when the files are not there."""
+
+    def __init__(self, dev, period=0.02):
+        import glob
+        import threading
+        self.period, self.samples, self._stop = period, [], threading.Event()
+        self.sclk = self.power = None
+        try:
+            d = _sysfs_device_dir(dev)
+            if d is not None:
+                if os.access(os.path.join(d, "pp_dpm_sclk"), os.R_OK):
+                    self.sclk = os.path.join(d, "pp_dpm_sclk")
+                for name in ("power1_average", "power1_input"):
+                    hit = glob.glob(os.path.join(d, "hwmon", "hwmon*", name))
+                    if hit and os.access(hit[0], os.R_OK):
+                        self.power = hit[0]
+                        break
+        except Exception:
+            pass
+        self._thread = threading.Thread(target=self._run, daemon=True)
+
+    def _read(self):
+        mhz = watts = None
+        try:
+            if self.sclk:
+                for line in open(self.sclk).read().splitlines():
+                    if line.strip().endswith("*"):
+                        mhz = int(line.split(":")[1].strip().split("Mhz")[0])
+            if self.power:
+                watts = int(open(self.power).read().strip()) / 1e6
+        except Exception:
+            pass
+        return mhz, watts
+
+    def _run(self):
+        t0 = time.perf_counter()
+        while not self._stop.is_set():
+            mhz, watts = self._read()
+            self.samples.append((round((time.perf_counter() - t0) * 1e3, 1), mhz, watts))
+            self._stop.wait(self.period)
+
+    def start(self):
+        if self.sclk or self.power:
+            self._thread.start()
+        return self
+
+    def stop(self):
+        self._stop.set()
+        if self._thread.is_alive():
+            self._thread.join()
+        mhz = [m for _, m, _ in self.samples if m is not None]
+        watts = [w for _, _, w in self.samples if w is not None]
+        return {"samples": len(self.samples), "period_ms": self.period * 1e3,
+                "sclk_mhz": {"min": min(mhz), "median": sorted(mhz)[len(mhz) // 2], "max": max(mhz)} if mhz else None,
+                "socket_watts": {"min": round(min(watts), 1), "median": round(sorted(watts)[len(watts) // 2], 1),
+                                 "max": round(max(watts), 1)} if watts else None,
+                "trace_ms_mhz_w": [(t, m, None if w is None else round(w)) for t, m, w in self.samples][:64]}
+
+
+def step_stats(step_ms):
+    s = sorted(step_ms)
+    return {"step_ms_min": round(s[0], 3), "step_ms_median": round(s[len(s) // 2], 3), "step_ms_max": round(s[-1], 3)}
 
 
 def pmc_traffic(label, symbol):
@@ -406,13 +484,35 @@ def main():
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
+    # timed region: K steps between two synchronisations.  Beside the wall clock: one HIP event per step (GPU
+    # time of every single step), the wall time of the enqueue loop alone (host cost), and the engine clock /
+    # socket power sampled from sysfs by a side thread -- so a slow line says WHY it is slow.
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    host_ms, gc_pauses = [], []
+
+    def gc_watch(phase, info, _t=[0.0]):          # interpreter garbage collections inside the timed region
+        if phase == "start":
+            _t[0] = time.perf_counter()
+        else:
+            gc_pauses.append({"generation": info["generation"], "ms": round((time.perf_counter() - _t[0]) * 1e3, 2),
+                              "in_step": len(host_ms)})
+    gc.callbacks.append(gc_watch)
+    sampler = SysfsSampler(dev).start()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
+        th = time.perf_counter()
         step()
+        marks[i + 1].record()
+        host_ms.append((time.perf_counter() - th) * 1e3)
+    t_enq = time.perf_counter() - t0
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
+    clocks = sampler.stop()
+    gc.callbacks.remove(gc_watch)
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
     # The dominant kernel's duration inside real training steps: HIP events around each of its
     # launches in two more steps of the same loop.  Kept out of the timed region above because an
     # event pair per launch (108 per step) costs the step ~14 %.
@@ -456,13 +556,40 @@ def main():
                                       "6 res blocks, D x6 (BASELINE.json configs[1])",
                           "global_batch": BASE["batch"] * world, "parallelism": f"dp{world}",
                           "precision": args.precision, **dist_info},
-               "step_tflops": round(GFLOP_PER_IMG * BASE["batch"] / (ms * 1e-3) / 1e3, 2)}
+               "step_tflops": round(GFLOP_PER_IMG * BASE["batch"] / (ms * 1e-3) / 1e3, 2),
+               # why the line reads what it reads: GPU time of every timed step (one HIP event per step), the host's
+               # share (wall time of the enqueue loop alone: when it is close to ms_per_step x steps the host, not
+               # the GPU, sets the pace), and the card's clock / power during the timed region
+               **step_stats(step_ms), "step_ms": [round(v, 2) for v in step_ms],
+               "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 3),
+               "host_step_ms": [round(v, 2) for v in host_ms], "gc_pauses_in_timed_region": gc_pauses,
+               "timed_region": clocks}
         if args.quick:
             print(json.dumps(res), flush=True)
             if dist is not None:
                 dist.barrier()
                 dist.destroy_process_group()
             return
+        if world == 1:
+            # the same loop over 200 more steps (~4-5 s): what the card sustains once clocks and power have settled
+            n_sus, win = 200, 20
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(n_sus // win + 1)]
+            sampler = SysfsSampler(dev, period=0.1).start()
+            torch.cuda.synchronize()
+            ts = time.perf_counter()
+            ev[0].record()
+            for i in range(n_sus):
+                step()
+                if (i + 1) % win == 0:
+                    ev[(i + 1) // win].record()
+            torch.cuda.synchronize()
+            dts = time.perf_counter() - ts
+            sus_clk = sampler.stop()
+            res["sustained"] = {"steps": n_sus, "ms_per_step": round(dts / n_sus * 1e3, 3),
+                                "value": round(BASE["batch"] * n_sus / dts, 2), "unit": "images/sec",
+                                "ms_per_step_by_window_of_20": [round(ev[i].elapsed_time(ev[i + 1]) / win, 2)
+                                                                for i in range(n_sus // win)],
+                                "sclk_mhz": sus_clk["sclk_mhz"], "socket_watts": sus_clk["socket_watts"]}
         res["roofline"] = dominant_kernel_roofline(args.precision, dev,
                                                    timer.mean_us("dominant") if timer.pairs else None,
                                                    timer.count("dominant"), symbol=timer.total() if timer.pairs else None)

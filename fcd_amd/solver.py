@@ -11,6 +11,7 @@ and the (optional) RCCL process group.
 """
 from __future__ import annotations
 
+import gc
 from argparse import Namespace
 from typing import Dict, Iterable, Optional
 
@@ -187,6 +188,8 @@ class FCDSolver(nn.Module):
         self.pair_d_calls = True                    # D step: D(x_real) and D(x_fake) as one paired-batch call
         self._pending = None
         self._val_cm = None
+        self.freeze_host_objects = True             # gc.freeze() after the first train_step (see there)
+        self._host_frozen = False
         self.build_model()
         self.D.register_forward_pre_hook(self._flush_pending)
         self.set_precision(getattr(config, "precision", "fp32"))
@@ -275,7 +278,10 @@ class FCDSolver(nn.Module):
     def _alpha(self, b, device):
         if self.alpha_override is not None:
             return self.alpha_override.to(device).contiguous().float()
-        return torch.rand(b, 1, 1, 1).to(device)
+        # the reference draws alpha from the CPU generator (fcd_solver.py:296) and copies it over; a pageable
+        # copy stops the host until the stream has drained, so the draw goes through pinned memory instead
+        a = torch.rand(b, 1, 1, 1)
+        return a.pin_memory().to(device, non_blocking=True) if device.type == "cuda" else a.to(device)
 
     def training_step(self, batch, batch_idx, optimizer_idx):
         x_real, c_org, c_trg, label_org, label_trg = batch
@@ -479,6 +485,16 @@ class FCDSolver(nn.Module):
         g_loss = self._run_optimizer(batch, batch_idx, 1, (self.global_step + 1) % self.n_critic == 0)
         self._flush_pending()          # no G update this step: nothing used D in between
         self.global_step += 1
+        if self.freeze_host_objects and not self._host_frozen:
+            # The interpreter's cyclic collector walks every tracked object on a full (generation 2) pass: with
+            # torch imported and both networks, arenas and packed operands built that is ~78-100 ms of stopped
+            # host -- four training steps of idle GPU -- and it recurs every few dozen steps (measured: bench.py's
+            # `gc_pauses_in_timed_region`).  After the first complete step everything long-lived exists: collect
+            # once, then move the survivors to the permanent generation so later passes only look at what the
+            # training loop itself allocates.  Collection stays enabled; nothing leaks.
+            gc.collect()
+            gc.freeze()
+            self._host_frozen = True
         return d_loss, g_loss
 
     # ---------------------------------------------------------------- validation --------
