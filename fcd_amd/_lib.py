@@ -17,6 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # FCD_HIP_LIB: another build of the same library (A/B timing of kernel variants in one GPU session)
 LIB_PATH = os.environ.get("FCD_HIP_LIB") or os.path.join(_HERE, "libfcd_hip.so")
 
+ABI_VERSION = 2    # include/fcd_hip.h: FCD_ABI_VERSION
 PREC_F32 = 0
 PREC_BF16 = 1
 PREC_BF16X3 = 2
@@ -61,6 +62,9 @@ PROTOTYPES = {
     "fcd_last_error": (C.c_char_p, []),
     "fcd_abi_version": (_I, []),
     "fcd_init": (_I, [_I]),
+    "fcd_conv_desc_bytes": (_I, []),
+    "fcd_wgrad_desc_bytes": (_I, []),
+    "fcd_set_overflow_flag": (_I, [_I, _P]),
     "fcd_last_conv_kernel": (C.c_char_p, []),
     "fcd_conv_workspace_bytes": (_Z, [C.POINTER(ConvDesc)]),
     "fcd_conv_gather": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
@@ -147,8 +151,12 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)   # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.fcd_abi_version() != 1:
-        raise RuntimeError("fcd_amd: libfcd_hip.so ABI version mismatch")
+    if lib.fcd_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"fcd_amd: libfcd_hip.so has ABI version {lib.fcd_abi_version()}, this binding needs {ABI_VERSION}")
+    if lib.fcd_conv_desc_bytes() != C.sizeof(ConvDesc) or lib.fcd_wgrad_desc_bytes() != C.sizeof(WgradDesc):
+        raise RuntimeError("fcd_amd: descriptor layouts of libfcd_hip.so and of this binding differ "
+                           f"(FcdConvDesc {lib.fcd_conv_desc_bytes()} / {C.sizeof(ConvDesc)} bytes, "
+                           f"FcdWgradDesc {lib.fcd_wgrad_desc_bytes()} / {C.sizeof(WgradDesc)} bytes)")
     _lib = lib
     return lib
 

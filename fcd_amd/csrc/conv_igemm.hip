@@ -41,6 +41,7 @@ struct GatherArgs {
   const float* w_amax;   // scaled by powers of two derived from them before the fp16 split
   unsigned* out_amax;    // optional: max |out| of this launch into FCD_AMAX_SLOTS per-block slots (pre-split kernels, no split-K)
   int out_amax_in_kernel; // host side: the launched kernel records out_amax itself (else the entry point runs fcd_absmax)
+  unsigned* ovf;          // FCD_PREC_F16X2: the caller's sticky overflow word (fcd_set_overflow_flag) or NULL
 };
 
 __device__ __forceinline__ float epilogue_value(float v, int co, long o, const GatherArgs& p) {
@@ -80,6 +81,7 @@ struct WgradArgs {
   int P, ND, splitk, ktiles, ktiles_per_split, tiles_m, tiles_n, accumulate;
   const float* g_amax;   // FCD_PREC_F16X2 (wgrad3_halo kernel): max |gs|, max |xb| (device scalars)
   const float* x_amax;
+  unsigned* ovf;         // FCD_PREC_F16X2: the caller's sticky overflow word (fcd_set_overflow_flag) or NULL
 };
 
 // slabs [splitk][O][KH*KW*IP] -> parameter layout [O][I][KH][KW].  One block per (o, ic input
@@ -207,9 +209,20 @@ __device__ __forceinline__ void unpack_f16(unsigned pk, float& lo, float& hi) {
   lo = (float)h[0];
   hi = (float)h[1];
 }
-// four fp32 (already scaled) -> (h, l) as two dwords each
-__device__ __forceinline__ void split2_f16(const u32x4 v, float s, uint2& h, uint2& l) {
+// Overflow guard of FCD_PREC_F16X2.  The scale comes from a max |.| that ANOTHER kernel recorded (norm.hip: block_absmax;
+// out_amax; fcd_absmax): a stale or under-estimated maximum would push scaled values past fp16's 65504 and turn the
+// result into Inf / NaN without any error.  Every split therefore folds max |scaled value| into a per-thread register
+// (`om`, two v_max3 per four values, branch-free), and the kernel's last act is ovf_report: a plain store of 1 to the
+// caller's sticky word when the thread saw a scaled value above 2^15 (the correct scale keeps them below 2^13).
+constexpr float F16X2_GUARD = 32768.f;
+__device__ __forceinline__ void ovf_report(float om, unsigned* flag) {
+  if (flag != nullptr && om > F16X2_GUARD) *flag = 1u;          // (v_max ignores NaN operands: they propagate as in fp32)
+}
+// four fp32 -> (h, l) of s * v as two dwords each
+__device__ __forceinline__ void split2_f16(const u32x4 v, float s, uint2& h, uint2& l, float& om) {
   const float f0 = __uint_as_float(v.x) * s, f1 = __uint_as_float(v.y) * s, f2 = __uint_as_float(v.z) * s, f3 = __uint_as_float(v.w) * s;
+  om = fmaxf(fmaxf(om, fabsf(f0)), fabsf(f1));
+  om = fmaxf(fmaxf(om, fabsf(f2)), fabsf(f3));
   h.x = cvt_pk_f16(f0, f1);
   h.y = cvt_pk_f16(f2, f3);
   float a0, a1, a2, a3;
@@ -220,10 +233,10 @@ __device__ __forceinline__ void split2_f16(const u32x4 v, float s, uint2& h, uin
 }
 
 // eight fp32 values -> two fp16x8 pieces of s * v, in the bf16x8_t register type the fragment structs use
-__device__ __forceinline__ void split2x8(const f32x8 f, float s, bf16x8_t& h, bf16x8_t& l) {
+__device__ __forceinline__ void split2x8(const f32x8 f, float s, bf16x8_t& h, bf16x8_t& l, float& om) {
   uint2 h0, l0, h1, l1;
-  split2_f16(u32x4{__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3])}, s, h0, l0);
-  split2_f16(u32x4{__float_as_uint(f[4]), __float_as_uint(f[5]), __float_as_uint(f[6]), __float_as_uint(f[7])}, s, h1, l1);
+  split2_f16(u32x4{__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3])}, s, h0, l0, om);
+  split2_f16(u32x4{__float_as_uint(f[4]), __float_as_uint(f[5]), __float_as_uint(f[6]), __float_as_uint(f[7])}, s, h1, l1, om);
   h = __builtin_bit_cast(bf16x8_t, u32x4{h0.x, h0.y, h1.x, h1.y});
   l = __builtin_bit_cast(bf16x8_t, u32x4{l0.x, l0.y, l1.x, l1.y});
 }
@@ -517,7 +530,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
     // all of tile `it`, whose stage takes the DMA of tile it+3, and tile it+1 has landed for the
     // split that runs under the second step's MFMAs.
     struct Pieces { bf16x8_t ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN]; };
-    float a_scale = 1.f;
+    float a_scale = 1.f, om = 0.f;         // om: max |scaled activation| this thread split (ovf_report)
     if constexpr (NP == 2) a_scale = pow2_scale(p.a_amax);
     // ---- AH: halo geometry, the staged next slice, the planes
     const int W2 = p.GW + 2, APX = (BM / p.GW + 2) * W2, PB = APX * 64;      // halo row pitch, halo pixels, plane bytes
@@ -555,7 +568,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
         const u32x4 v = hst[j];
         if constexpr (NP == 2) {
           uint2 h2, l2;
-          split2_f16(v, a_scale, h2, l2);
+          split2_f16(v, a_scale, h2, l2, om);
           *reinterpret_cast<uint2*>(dst) = h2;
           *reinterpret_cast<uint2*>(dst + PB) = l2;
           continue;
@@ -588,7 +601,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
         } else {
           const int r = wm * WTM + mi * 32 + lr, sw = (r >> 1) & 7;
           const float4 lo = As[r * 8 + (c0 ^ sw)], hi = As[r * 8 + ((c0 + 1) ^ sw)];
-          if constexpr (NP == 2) split2x8(f32x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w}, a_scale, P.ah[mi], P.al[mi]);
+          if constexpr (NP == 2) split2x8(f32x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w}, a_scale, P.ah[mi], P.al[mi], om);
           else split3(f32x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w}, P.ah[mi], P.am[mi], P.al[mi]);
         }
       }
@@ -790,6 +803,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
     }
     }
     wait_vmcnt<0>();
+    if constexpr (NP == 2) ovf_report(om, p.ovf);
   } else {
 #pragma unroll
   for (int s = 0; s < S - 1; ++s) {
@@ -1544,11 +1558,12 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3p_kernel(const WgradArgs p, 
 #pragma unroll
   for (int i = 0; i < BL; ++i) b_st[i] = NP * A_PLANE + plane_off(b_row + RPB * i, b_c4 >> 1, B_ROW) + 8 * (b_c4 & 1);
   float sg = 1.f, sx = 1.f;
+  float om = 0.f;      // max |scaled operand| this thread split (ovf_report)
   if constexpr (NP == 2) { sg = pow2_scale(p.g_amax); sx = pow2_scale(p.x_amax); }
   auto split_store = [&](const u32x4 v, unsigned char* dst, int plane_bytes, float sc) {
     if constexpr (NP == 2) {
       uint2 h2, l2;
-      split2_f16(v, sc, h2, l2);
+      split2_f16(v, sc, h2, l2, om);
       *reinterpret_cast<uint2*>(dst) = h2;
       *reinterpret_cast<uint2*>(dst + plane_bytes) = l2;
       return;
@@ -1679,6 +1694,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3p_kernel(const WgradArgs p, 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] += acc2[i][j][r];
   const float isc = NP == 2 ? (1.f / sg) * (1.f / sx) : 1.f;     // powers of two: exact
+  if constexpr (NP == 2) ovf_report(om, p.ovf);
   // D[row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)][col = lane&31] of sub-tile (mi, ni)
   float* __restrict__ dst = p.slab + (long)ks * p.O * p.ND;
   const int lr = lane & 31, lh = lane >> 5;
@@ -1810,6 +1826,7 @@ __global__ __launch_bounds__(64 * (H7_WAVES + 1)) void wgrad7_halo_x3_kernel(con
   __shared__ __attribute__((aligned(16))) unsigned char Xp[8 * XSLOT];
   __shared__ __attribute__((aligned(16))) unsigned char Gp[2 * GBUF];
   float sg = 1.f, sx = 1.f;
+  float om = 0.f;      // max |scaled operand| this thread split (ovf_report)
   if constexpr (NP == 2) { sg = pow2_scale(p.g_amax); sx = pow2_scale(p.x_amax); }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1840,7 +1857,7 @@ __global__ __launch_bounds__(64 * (H7_WAVES + 1)) void wgrad7_halo_x3_kernel(con
   auto split_store = [&](const u32x4 v, unsigned char* dst, int plane_bytes, float sc) {
     if constexpr (NP == 2) {
       uint2 h2, l2;
-      split2_f16(v, sc, h2, l2);
+      split2_f16(v, sc, h2, l2, om);
       *reinterpret_cast<uint2*>(dst) = h2;
       *reinterpret_cast<uint2*>(dst + plane_bytes) = l2;
       return;
@@ -1887,6 +1904,7 @@ __global__ __launch_bounds__(64 * (H7_WAVES + 1)) void wgrad7_halo_x3_kernel(con
       for (int j = 0; j < 4; ++j) ng[j] = load_g(lane + 64 * j, y + 2);
       __syncthreads();
     }
+    if constexpr (NP == 2) ovf_report(om, p.ovf);
     return;
   }
 
@@ -1935,6 +1953,7 @@ __global__ __launch_bounds__(64 * (H7_WAVES + 1)) void wgrad7_halo_x3_kernel(con
   // D[o = 4 kq + e][i = c16] of tap (th, t)
   float* __restrict__ dst = p.slab + (long)((n * R + r) * nch + ch) * p.O * p.ND;
   const float isc = NP == 2 ? (1.f / sg) * (1.f / sx) : 1.f;      // powers of two: exact
+  if constexpr (NP == 2) ovf_report(om, p.ovf);
 #pragma unroll
   for (int t = 0; t < 7; ++t) {
     const int col = (th * 7 + t) * p.IP + cg * 16 + c16;
@@ -2062,6 +2081,7 @@ __global__ __launch_bounds__(64 * (H7_WAVES + 1)) void conv7_halo_x3_kernel(cons
   constexpr int F7X_SLOT = NP * F7X_PLANE;
   __shared__ __attribute__((aligned(16))) unsigned char Xp[8 * F7X_SLOT];
   float a_scale = 1.f, w_scale = 1.f;
+  float om = 0.f;      // max |scaled operand| this thread split (ovf_report)
   if constexpr (NP == 2) { a_scale = pow2_scale(p.a_amax); w_scale = pow2_scale(p.w_amax); }
   __shared__ __attribute__((aligned(16))) float Rs[2 * H7_WAVES * F7_CW * 16];   // [row parity][wave][pixel][16 co]
   const int tid = threadIdx.x, lane = tid & 63;
@@ -2085,7 +2105,7 @@ __global__ __launch_bounds__(64 * (H7_WAVES + 1)) void conv7_halo_x3_kernel(cons
     unsigned char* dst = Xp + ((yy + 16) & 7) * F7X_SLOT + lpx * 128 + (((c4 >> 1) ^ (lpx & 7)) << 4) + 8 * (c4 & 1);
     if constexpr (NP == 2) {
       uint2 h2, l2;
-      split2_f16(v, a_scale, h2, l2);
+      split2_f16(v, a_scale, h2, l2, om);
       *reinterpret_cast<uint2*>(dst) = h2;
       *reinterpret_cast<uint2*>(dst + F7X_PLANE) = l2;
       return;
@@ -2151,6 +2171,7 @@ __global__ __launch_bounds__(64 * (H7_WAVES + 1)) void conv7_halo_x3_kernel(cons
       __syncthreads();                     // row y+4 visible, partial tiles of row y complete
     }
     sum_store(y1 - 1);
+    if constexpr (NP == 2) ovf_report(om, p.ovf);
     return;
   }
 
@@ -2168,7 +2189,7 @@ __global__ __launch_bounds__(64 * (H7_WAVES + 1)) void conv7_halo_x3_kernel(cons
     } else {
       f = f32x8{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     }
-    if constexpr (NP == 2) split2x8(f, w_scale, wh[s2], wl[s2]);
+    if constexpr (NP == 2) split2x8(f, w_scale, wh[s2], wl[s2], om);
     else split3(f, wh[s2], wm[s2], wl[s2]);
   }
   const float isc = NP == 2 ? (1.f / a_scale) * (1.f / w_scale) : 1.f;      // powers of two: exact
@@ -2221,6 +2242,7 @@ __global__ __launch_bounds__(64 * (H7_WAVES + 1)) void conv7_halo_x3_kernel(cons
       for (int e = 0; e < 4; ++e) R[(16 * mt + 4 * kq + e) * 16 + c16] = (acc[mt][e] + (acca[mt][e] + accb[mt][e])) * isc;
     __syncthreads();
   }
+  if constexpr (NP == 2) ovf_report(om, p.ovf);      // the weights this wave split
 }
 
 // 7x7, stride-1, pad-3 convolution from 12 physical channels to 64 (the generator's first layer, 11 -> 64,
@@ -2245,6 +2267,7 @@ __global__ __launch_bounds__(64 * (C12_WAVES + 1)) void conv7_c12_halo_x3_kernel
   constexpr int C12_SLOTN = NP * C12_ROWB;
   __shared__ __attribute__((aligned(16))) unsigned char Xp[8 * C12_SLOTN];
   float a_scale = 1.f, w_scale = 1.f;
+  float om = 0.f;      // max |scaled operand| this thread split (ovf_report)
   if constexpr (NP == 2) { a_scale = pow2_scale(p.a_amax); w_scale = pow2_scale(p.w_amax); }
   __shared__ __attribute__((aligned(16))) float Rs[2 * C12_WAVES * 32 * 64];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -2268,7 +2291,7 @@ __global__ __launch_bounds__(64 * (C12_WAVES + 1)) void conv7_c12_halo_x3_kernel
     unsigned char* dst = Xp + ((yy + 16) & 7) * C12_SLOTN + lpx * 24 + lc4 * 8;
     if constexpr (NP == 2) {
       uint2 h2, l2;
-      split2_f16(v, a_scale, h2, l2);
+      split2_f16(v, a_scale, h2, l2, om);
       *reinterpret_cast<uint2*>(dst) = h2;
       *reinterpret_cast<uint2*>(dst + C12_ROWB) = l2;
       return;
@@ -2351,6 +2374,7 @@ __global__ __launch_bounds__(64 * (C12_WAVES + 1)) void conv7_c12_halo_x3_kernel
         }
       }
     }
+    if constexpr (NP == 2) ovf_report(om, p.ovf);
     return;
   }
 
@@ -2368,7 +2392,7 @@ __global__ __launch_bounds__(64 * (C12_WAVES + 1)) void conv7_c12_halo_x3_kernel
       f32x8 f;
 #pragma unroll
       for (int j = 0; j < 8; ++j) f[j] = (co < p.Cout && k0 + j < 84) ? src[j] : 0.f;
-      if constexpr (NP == 2) split2x8(f, w_scale, wh[ks][ni], wl[ks][ni]);
+      if constexpr (NP == 2) split2x8(f, w_scale, wh[ks][ni], wl[ks][ni], om);
       else split3(f, wh[ks][ni], wm[ks][ni], wl[ks][ni]);
     }
   __syncthreads();
@@ -2425,6 +2449,7 @@ __global__ __launch_bounds__(64 * (C12_WAVES + 1)) void conv7_c12_halo_x3_kernel
     }
   }
   __syncthreads();
+  if constexpr (NP == 2) ovf_report(om, p.ovf);      // the weights this wave split
 }
 
 // Weight gradient of a 3x3, stride-1, pad-1 convolution on 32-pixel-wide images (the residual blocks), FCD_PREC_BF16X3,
@@ -2483,11 +2508,12 @@ __global__ __launch_bounds__(64 * W3_WAVES) void wgrad3_halo_x3_kernel(const Wgr
     return __builtin_amdgcn_raw_buffer_load_b128(rgs, (int)voff, 0, 0);
   };
   float sg = 1.f, sx = 1.f;
+  float om = 0.f;      // max |scaled operand| this thread split (ovf_report)
   if constexpr (NP == 2) { sg = pow2_scale(p.g_amax); sx = pow2_scale(p.x_amax); }
   auto split_store = [&](const u32x4 v, unsigned char* dst, int plane_bytes, float sc) {
     if constexpr (NP == 2) {
       uint2 h2, l2;
-      split2_f16(v, sc, h2, l2);
+      split2_f16(v, sc, h2, l2, om);
       *reinterpret_cast<uint2*>(dst) = h2;
       *reinterpret_cast<uint2*>(dst + plane_bytes) = l2;
       return;
@@ -2613,6 +2639,7 @@ __global__ __launch_bounds__(64 * W3_WAVES) void wgrad3_halo_x3_kernel(const Wgr
   // D[o = 64 ob + 16 (2 oh + ot) + 4 kq + e][ci = 64 cb + 16 cq + c16] of tap t
   float* __restrict__ dst = p.slab + (long)split * p.O * p.ND;
   const float isc = NP == 2 ? (1.f / sg) * (1.f / sx) : 1.f;      // powers of two: exact
+  if constexpr (NP == 2) ovf_report(om, p.ovf);
 #pragma unroll
   for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
@@ -2645,6 +2672,7 @@ __global__ __launch_bounds__(64 * (C12_WAVES + 1)) void wgrad7_c12_halo_x3_kerne
   __shared__ __attribute__((aligned(16))) unsigned char Xp[8 * XSLOT];          // (columns 84 .. 95 of the last pixels stay inside the 72-pixel row)
   __shared__ __attribute__((aligned(16))) unsigned char Gp[2 * GBUF];
   float sg = 1.f, sx = 1.f;
+  float om = 0.f;      // max |scaled operand| this thread split (ovf_report)
   if constexpr (NP == 2) { sg = pow2_scale(p.g_amax); sx = pow2_scale(p.x_amax); }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2674,7 +2702,7 @@ __global__ __launch_bounds__(64 * (C12_WAVES + 1)) void wgrad7_c12_halo_x3_kerne
   auto split_store = [&](const u32x4 v, unsigned char* dst, int plane_bytes, float sc) {
     if constexpr (NP == 2) {
       uint2 h2, l2;
-      split2_f16(v, sc, h2, l2);
+      split2_f16(v, sc, h2, l2, om);
       *reinterpret_cast<uint2*>(dst) = h2;
       *reinterpret_cast<uint2*>(dst + plane_bytes) = l2;
       return;
@@ -2718,6 +2746,7 @@ __global__ __launch_bounds__(64 * (C12_WAVES + 1)) void wgrad7_c12_halo_x3_kerne
       for (int j = 0; j < 8; ++j) ng[j] = load_g(lane + 64 * j, y + 2);
       __syncthreads();
     }
+    if constexpr (NP == 2) ovf_report(om, p.ovf);
     return;
   }
 
@@ -2784,6 +2813,7 @@ __global__ __launch_bounds__(64 * (C12_WAVES + 1)) void wgrad7_c12_halo_x3_kerne
   float* __restrict__ dst = p.slab + (long)((n * R + r) * nch + ch) * p.O * p.ND;
   const int lr = lane & 31, lh = lane >> 5;
   const float isc = NP == 2 ? (1.f / sg) * (1.f / sx) : 1.f;      // powers of two: exact
+  if constexpr (NP == 2) ovf_report(om, p.ovf);
 #pragma unroll
   for (int t = 0; t < 3; ++t) {
     const int j = 32 * t + lr;
@@ -2889,32 +2919,36 @@ __global__ __launch_bounds__(256) void pack_adj_x3_kernel(const float* __restric
 }
 
 // FCD_PREC_F16X2 operands: two fp16 planes (h, l) of s * w, s = pow2_scale(max |w|); same element orders as the x3 packs
-__device__ __forceinline__ void store_split2(unsigned short* __restrict__ out, long plane_stride, long idx, float v) {
+__device__ __forceinline__ void store_split2(unsigned short* __restrict__ out, long plane_stride, long idx, float v, float& om) {
+  om = fmaxf(om, fabsf(v));
   const _Float16 h = (_Float16)v;
   const _Float16 l = (_Float16)(v - (float)h);
   out[idx] = __builtin_bit_cast(unsigned short, h);
   out[plane_stride + idx] = __builtin_bit_cast(unsigned short, l);
 }
 __device__ __forceinline__ void pack_fwd_h2_body(const float* __restrict__ w, unsigned short* __restrict__ out,
-                                                 int O, int I, int IP, int taps, const float* __restrict__ amax) {
+                                                 int O, int I, int IP, int taps, const float* __restrict__ amax, unsigned* ovf) {
   const float sc = pow2_scale(amax);
+  float om = 0.f;
   const long total = (long)O * taps * IP;
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
     const int i = (int)(idx % IP);
     const long t2 = idx / IP;
     const int tap = (int)(t2 % taps), o = (int)(t2 / taps);
-    store_split2(out, total, idx, i < I ? sc * w[((long)o * I + i) * taps + tap] : 0.f);
+    store_split2(out, total, idx, i < I ? sc * w[((long)o * I + i) * taps + tap] : 0.f, om);
   }
+  ovf_report(om, ovf);
 }
 __global__ __launch_bounds__(256) void pack_fwd_h2_kernel(const float* __restrict__ w, unsigned short* __restrict__ out,
-                                                          int O, int I, int IP, int taps, const float* __restrict__ amax) {
-  pack_fwd_h2_body(w, out, O, I, IP, taps, amax);
+                                                          int O, int I, int IP, int taps, const float* __restrict__ amax, unsigned* ovf) {
+  pack_fwd_h2_body(w, out, O, I, IP, taps, amax, ovf);
 }
 // out[phase][plane][i][th][tw][o], element order of pack_adj_x3_kernel
 __device__ __forceinline__ void pack_adj_h2_body(const float* __restrict__ w, unsigned short* __restrict__ out,
                                                  int O, int OP, int I, int KH, int KW, int stride,
-                                                 const float* __restrict__ amax) {
+                                                 const float* __restrict__ amax, unsigned* ovf) {
   const float sc = pow2_scale(amax);
+  float om = 0.f;
   const int TH = stride == 1 ? KH : 2, TW = stride == 1 ? KW : 2;
   const int nph = stride == 1 ? 1 : 4;
   const long per_phase = (long)I * TH * TW * OP;
@@ -2935,13 +2969,14 @@ __device__ __forceinline__ void pack_adj_h2_body(const float* __restrict__ w, un
       kw = 3 - (ph & 1) - 2 * tw;
     }
     store_split2(out + (long)ph * 2 * per_phase, per_phase, idx - (long)ph * per_phase,
-                 o < O ? sc * w[(((long)o * I + i) * KH + kh) * KW + kw] : 0.f);
+                 o < O ? sc * w[(((long)o * I + i) * KH + kh) * KW + kw] : 0.f, om);
   }
+  ovf_report(om, ovf);
 }
 __global__ __launch_bounds__(256) void pack_adj_h2_kernel(const float* __restrict__ w, unsigned short* __restrict__ out,
                                                           int O, int OP, int I, int KH, int KW, int stride,
-                                                          const float* __restrict__ amax) {
-  pack_adj_h2_body(w, out, O, OP, I, KH, KW, stride, amax);
+                                                          const float* __restrict__ amax, unsigned* ovf) {
+  pack_adj_h2_body(w, out, O, OP, I, KH, KW, stride, amax, ovf);
 }
 // The same packs for up to FCD_PACK_BATCH_MAX weights of one shape in one launch (blockIdx.y = weight): a network's
 // twelve residual-block convolutions are re-packed after every optimizer step, 24 launches of 6 - 9 us each
@@ -2949,12 +2984,13 @@ struct PackBatch {
   const float* w[FCD_PACK_BATCH_MAX];
   unsigned short* out[FCD_PACK_BATCH_MAX];
   const float* amax[FCD_PACK_BATCH_MAX];
+  unsigned* ovf;
 };
 __global__ __launch_bounds__(256) void pack_fwd_h2_batch_kernel(const PackBatch b, int O, int I, int IP, int taps) {
-  pack_fwd_h2_body(b.w[blockIdx.y], b.out[blockIdx.y], O, I, IP, taps, b.amax[blockIdx.y]);
+  pack_fwd_h2_body(b.w[blockIdx.y], b.out[blockIdx.y], O, I, IP, taps, b.amax[blockIdx.y], b.ovf);
 }
 __global__ __launch_bounds__(256) void pack_adj_h2_batch_kernel(const PackBatch b, int O, int OP, int I, int KH, int KW, int stride) {
-  pack_adj_h2_body(b.w[blockIdx.y], b.out[blockIdx.y], O, OP, I, KH, KW, stride, b.amax[blockIdx.y]);
+  pack_adj_h2_body(b.w[blockIdx.y], b.out[blockIdx.y], O, OP, I, KH, KW, stride, b.amax[blockIdx.y], b.ovf);
 }
 
 // Demangled symbol (as rocprofv3 prints it, without namespace and argument list) of the last convolution /
@@ -3076,6 +3112,7 @@ void fill_gather_args(const FcdConvDesc* d, GatherArgs& a) {
   a.stats = nullptr;
   a.stats_cpp = 0;
   a.a_amax = a.w_amax = nullptr;
+  a.ovf = nullptr;
   a.out_amax = nullptr;
   a.out_amax_in_kernel = 0;
 }
@@ -3365,6 +3402,7 @@ extern "C" int fcd_conv_gather(const FcdConvDesc* d, const float* in, const floa
   a.in = in; a.w = w_packed; a.bias = bias; a.mask = mask_src; a.res = residual; a.out = out;
   a.slab = (float*)workspace;
   a.a_amax = a_amax; a.w_amax = w_amax;
+  a.ovf = a_amax ? fcd_overflow_flag_current() : nullptr;
   a.out_amax = reinterpret_cast<unsigned*>(d->out_amax);
   rc = run_gather(d, a, fcd_stream(stream));
   if (rc == FCD_OK && d->out_amax && !a.out_amax_in_kernel)
@@ -3425,6 +3463,7 @@ int conv_stats_impl(const FcdConvDesc* d, const float* in, const float* w_packed
   a.in = in; a.w = w_packed; a.bias = nullptr; a.mask = nullptr; a.res = nullptr; a.out = out;
   a.slab = (float*)workspace;
   a.a_amax = a_amax; a.w_amax = w_amax;
+  a.ovf = a_amax ? fcd_overflow_flag_current() : nullptr;
   const int chunks = fused_stats_chunks(d);
   const long hw = (long)d->OH * d->OW;
   if (chunks == 0) {   // shape does not allow the fused form: convolution, then the two-pass statistics
@@ -3598,6 +3637,7 @@ extern "C" int fcd_conv_wgrad(const FcdWgradDesc* d, const float* gsmall, const 
   a.splitk = fcd_cdiv(a.ktiles, a.ktiles_per_split);
   a.accumulate = d->accumulate;
   a.g_amax = a.x_amax = nullptr;
+  a.ovf = want_h2 ? fcd_overflow_flag_current() : nullptr;
   {
     // 32-bit lane offsets inside a workgroup's window: its pixel rows of gs, the images those touch of xb
     const size_t px = (size_t)a.ktiles_per_split * 32;
@@ -3794,7 +3834,7 @@ extern "C" int fcd_pack_weight_fwd_h2(const float* w, void* packed, const float*
   const long total = (long)O * KH * KW * IP;
   const int blocks = (int)std::min<long>(fcd_cdiv(total, 256), 4096);
   hipLaunchKernelGGL(pack_fwd_h2_kernel, dim3(blocks), dim3(256), 0, fcd_stream(stream), w, (unsigned short*)packed, O, I, IP,
-                     KH * KW, w_amax);
+                     KH * KW, w_amax, fcd_overflow_flag_current());
   return fcd_check_launch("pack_weight_fwd_h2");
 }
 
@@ -3806,7 +3846,7 @@ extern "C" int fcd_pack_weight_adj_h2(const float* w, void* packed, const float*
   const long total = (long)nph * I * TH * TW * OP;
   const int blocks = (int)std::min<long>(fcd_cdiv(total, 256), 4096);
   hipLaunchKernelGGL(pack_adj_h2_kernel, dim3(blocks), dim3(256), 0, fcd_stream(stream), w, (unsigned short*)packed, O, OP, I,
-                     KH, KW, stride, w_amax);
+                     KH, KW, stride, w_amax, fcd_overflow_flag_current());
   return fcd_check_launch("pack_weight_adj_h2");
 }
 
@@ -3818,6 +3858,7 @@ int fill_pack_batch(PackBatch& b, const float* const* w, void* const* packed, co
     const int j = i < count ? i : 0;
     FCD_REQUIRE(w[j] && packed[j] && w_amax[j], "pack_weight_h2_batch: null tensor");
     b.w[i] = w[j]; b.out[i] = (unsigned short*)packed[j]; b.amax[i] = w_amax[j];
+    b.ovf = fcd_overflow_flag_current();
   }
   return FCD_OK;
 }

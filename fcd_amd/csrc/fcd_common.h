@@ -24,6 +24,9 @@ int fcd_finalize_apply(const double* partial, const float* z, float* mean, float
 // fcd_instnorm_stats_noalloc (hipGetSymbolAddress, once per device; `device` must be current).
 int fcd_noalloc_scratch_init(int device);
 
+// runtime.hip: the current device's overflow word of FCD_PREC_F16X2 (fcd_set_overflow_flag), or NULL
+unsigned* fcd_overflow_flag_current(void);
+
 #define FCD_REQUIRE(cond, ...)            \
   do {                                    \
     if (!(cond)) {                        \

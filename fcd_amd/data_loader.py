@@ -104,6 +104,15 @@ class L8BiomePatchPool:
     def __len__(self) -> int:
         return int(self.indices.shape[0])
 
+    _bad_positions = None
+
+    def check_positions(self) -> None:
+        """Raise IndexError if any device-resident ``positions`` handed to :meth:`gather` since the last call was out of
+        range (one device-to-host copy; host-resident positions are checked in ``gather`` itself)."""
+        bad, self._bad_positions = self._bad_positions, None
+        if bad is not None and bool(bad.item()):
+            raise IndexError("patch position outside the pool (device-resident positions; the gather used clamped ones)")
+
     def gather(self, positions: torch.Tensor, aug: Optional[torch.Tensor] = None, ret_mask: bool = False):
         """positions: int64 positions into the pool's (selected, possibly shuffled) index list."""
         if positions.numel() == 0:
@@ -112,8 +121,15 @@ class L8BiomePatchPool:
             # range check on the host, before the upload: no device-to-host sync in the batch loop
             if int(positions.min()) < 0 or int(positions.max()) >= len(self):
                 raise IndexError("patch position outside the pool")
-        positions = positions.to(self.device, torch.int64)
-        # (positions already on the device: torch's indexing kernel asserts the range itself)
+            positions = positions.to(self.device, torch.int64)
+        else:
+            # positions already on the device: no host sync here, and no device-side assert either (it would abort
+            # the HIP context and poison the process): out-of-range positions are clamped for the gather and
+            # remembered in a device flag that check_positions() turns into the IndexError
+            positions = positions.to(self.device, torch.int64)
+            bad = ((positions < 0) | (positions >= len(self))).any()
+            self._bad_positions = bad if self._bad_positions is None else (self._bad_positions | bad)
+            positions = positions.clamp(0, len(self) - 1)
         index = self.indices[positions].contiguous()
         if aug is not None:
             aug = aug.to(self.device, torch.int32).contiguous()

@@ -129,11 +129,46 @@ def weight_format(d: ConvDesc) -> int:
     return int(L.load().fcd_conv_weight_format(C.byref(d)))
 
 
+_OVERFLOW = {}     # device index -> int32 word registered with fcd_set_overflow_flag
+
+
+def overflow_flag(device) -> torch.Tensor:
+    """The device's sticky overflow word of PREC_F16X2 (``fcd_set_overflow_flag``): every fp32x2 kernel and weight
+    pack stores 1 to it when a scaled operand exceeds 2^15 (a stale or under-estimated max |.|).
+    Created, zeroed and registered on first use; it lives as long as the process."""
+    idx = torch.device(device).index
+    if idx is None:
+        idx = torch.cuda.current_device()
+    t = _OVERFLOW.get(idx)
+    if t is None:
+        t = torch.zeros(1, dtype=torch.int32, device=torch.device("cuda", idx))
+        L.check(L.load().fcd_set_overflow_flag(idx, t.data_ptr()), "fcd_set_overflow_flag")
+        _OVERFLOW[idx] = t
+    return t
+
+
+def check_overflow(device, reset: bool = True) -> None:
+    """Poll the overflow word (one device-to-host copy: a synchronisation point) and raise if it is set."""
+    idx = torch.device(device).index
+    if idx is None:
+        idx = torch.cuda.current_device()
+    t = _OVERFLOW.get(idx)
+    if t is None:
+        return
+    if int(t.item()) != 0:
+        if reset:
+            t.zero_()
+        raise RuntimeError("fcd_amd: fp32x2 overflow guard: a scaled operand exceeded 2^15 in a kernel on "
+                           f"cuda:{idx} -- the max |.| attached to a descriptor (a_amax / w_amax / g_amax / x_amax) was "
+                           "stale or too small for the tensor it describes; results since the last check may hold Inf / NaN")
+
+
 def _amax_ptr(t: Optional[torch.Tensor]):
     if t is None:
         return None
     if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous() or t.numel() < AMAX_SLOTS or t.data_ptr() % 16:
         raise ValueError("an amax operand is a contiguous float32 device tensor of AMAX_SLOTS (1024) partial maxima, 16-byte aligned")
+    overflow_flag(t.device)      # fp32x2 in use on this device: make sure its overflow word is registered
     return t.data_ptr()
 
 

@@ -147,6 +147,9 @@ class GradSync:
                     t.data.copy_(h)
                 else:
                     dist.broadcast(t.data, 0, group=self.group)
+                # written through .data: bump the version so that everything keyed on (data_ptr, _version) -- packed
+                # operands, the fp32x2 weight maxima, folded eval weights -- is rebuilt from the new values
+                torch.autograd.graph.increment_version(t)
 
 
 class BucketedReducer:

@@ -189,6 +189,7 @@ class FCDSolver(nn.Module):
         self._pending = None
         self._val_cm = None
         self.freeze_host_objects = True             # gc.freeze() after the first train_step (see there)
+        self.overflow_check_every = 64              # fp32x2: poll the overflow word every so many train steps
         self._host_frozen = False
         self.build_model()
         self.D.register_forward_pre_hook(self._flush_pending)
@@ -485,6 +486,10 @@ class FCDSolver(nn.Module):
         g_loss = self._run_optimizer(batch, batch_idx, 1, (self.global_step + 1) % self.n_critic == 0)
         self._flush_pending()          # no G update this step: nothing used D in between
         self.global_step += 1
+        if self.precision == "fp32x2" and (self.global_step == 1 or self.global_step % self.overflow_check_every == 0):
+            # fp32x2's overflow guard (include/fcd_hip.h: fcd_set_overflow_flag): polled after the first step, where a
+            # mis-wired maximum shows, and then every `overflow_check_every` steps (a poll is a host-device sync)
+            ops.check_overflow(self.device)
         if self.freeze_host_objects and not self._host_frozen:
             # The interpreter's cyclic collector walks every tracked object on a full (generation 2) pass: with
             # torch imported and both networks, arenas and packed operands built that is ~78-100 ms of stopped
@@ -521,6 +526,7 @@ class FCDSolver(nn.Module):
             self.grad_sync.sum_counts(self._val_cm)
         cm = np.zeros((2, 2), dtype=np.int64) if self._val_cm is None else self._val_cm.cpu().numpy()
         self._val_cm = None
+        self.check_overflow()
         # the figures of the reference's "Validation Result" line (metrics.accuracy / iou_score / f1_score)
         res = {"confusion_matrix": cm, "Accuracy": accuracy(cm), "IoU": iou_score(cm), "F1": f1_score(cm)}
         if self._scheds is not None:
@@ -529,6 +535,11 @@ class FCDSolver(nn.Module):
             for sched in self._scheds:
                 sched.step(res["F1"])
         return res
+
+    def check_overflow(self) -> None:
+        """fp32x2 only: raise if any kernel since the last poll saw a scaled operand beyond 2^15 (stale max |.|)."""
+        if self.precision == "fp32x2" and self.device.type == "cuda":
+            ops.check_overflow(self.device)
 
     def sync_running_stats(self) -> None:
         """Data parallel: give every rank rank 0's tracked InstanceNorm running statistics (what DDP's
@@ -543,6 +554,7 @@ class FCDSolver(nn.Module):
         update is finished first).  Data parallel: call :meth:`sync_running_stats` on ALL ranks before
         rank 0 saves (it is a collective, so it is not hidden in here)."""
         self._flush_pending()
+        self.check_overflow()
         return super().state_dict(*args, **kwargs)
 
     # ---------------------------------------------------------------- inference ---------
@@ -590,7 +602,9 @@ class FCDSolver(nn.Module):
             # until the loop is done (no per-batch device-to-host copy)
             out.append(ops.pseudo_mask(diff, target, float(threshold), cm=cm if target is not None else None))
         self.pseudo_mask_cm = None if cm is None else cm.cpu().numpy()     # cm[truth][prediction], fcd_solver.py:764-769
-        return torch.cat(out).cpu().numpy()
+        masks = torch.cat(out).cpu().numpy()
+        self.check_overflow()
+        return masks
 
     generate_masks = make_psuedo_masks
 

@@ -30,7 +30,10 @@
 extern "C" {
 #endif
 
-#define FCD_ABI_VERSION 1
+/* 2: FcdConvDesc grew a_amax / w_amax / out_amax and FcdWgradDesc g_amax / x_amax (FCD_PREC_F16X2): a caller built
+ * against version 1 would hand over descriptors that are too short.  Check fcd_abi_version() == FCD_ABI_VERSION and
+ * fcd_conv_desc_bytes() / fcd_wgrad_desc_bytes() == sizeof of your own structs before the first call. */
+#define FCD_ABI_VERSION 2
 
 #define FCD_OK 0
 #define FCD_EINVAL (-1)   /* bad descriptor / shape / alignment            */
@@ -53,8 +56,22 @@ extern "C" {
 
 const char* fcd_last_error(void);
 int fcd_abi_version(void);
+/* sizeof(FcdConvDesc) / sizeof(FcdWgradDesc) as this build of the library sees them (a binding compares them with
+ * its own struct sizes: a mismatch means mixed versions of header and library).  No reference counterpart. */
+int fcd_conv_desc_bytes(void);
+int fcd_wgrad_desc_bytes(void);
 /* Checks that `device` is a gfx950 part and makes it current. */
 int fcd_init(int device);
+/* Overflow guard of FCD_PREC_F16X2 (no reference counterpart: the reference computes in plain fp32).  The scaled
+ * fp16 pieces rely on max |.| values that OTHER kernels recorded (a_amax, w_amax, g_amax, x_amax); a stale or
+ * under-estimated maximum would overflow fp16 (65504) and yield Inf / NaN silently.  Register one device word per
+ * GPU (4-byte aligned, zeroed by the caller, owned by the caller; NULL unregisters): every FCD_PREC_F16X2 kernel and
+ * weight pack stores 1 to it (plain store, sticky) when a scaled operand exceeds 2^15 -- four times what a correct
+ * maximum allows (a NaN operand is not an overflow: it propagates into the result as in fp32).  The caller polls the
+ * word whenever it likes (it costs a device-to-host copy) and zeroes it again.  Guarantee with a correct maximum: operands are represented to 2^-22 relative for every element
+ * within 2^-15 of the tensor's maximum (two 11-bit pieces); smaller elements keep an ABSOLUTE error below
+ * 2^-37 x the tensor's maximum (the low piece becomes subnormal), i.e. they lose relative, not absolute accuracy. */
+int fcd_set_overflow_flag(int device, uint32_t* flag);
 
 /* ------------------------------------------------------------------------- *
  * Implicit-GEMM convolution, "gather" form.

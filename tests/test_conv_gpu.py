@@ -848,3 +848,123 @@ def test_pack_weight_h2_batch(dev, geom):
             assert outs[j].shape == ref.shape and torch.equal(outs[j].view(torch.int16), ref.view(torch.int16)), (kind, j)
     with pytest.raises(RuntimeError):
         ops.pack_weight_h2_batch("fwd", [ws[0], torch.randn(O, I + 4, k, k, device=dev)], g, [amax[0], amax[1]])
+
+
+@pytest.mark.parametrize("log2_disparity", [10, 18])
+def test_f16x2_per_sample_disparity(dev, log2_disparity):
+    """fp32x2 scales a whole operand tensor by ONE power of two taken from its max |.|.  One of 32 samples here is
+    2^10 / 2^18 times larger than the other 31 (the paired generator call puts different chains into one tensor): the
+    small samples sit 2^-10 / 2^-18 below the maximum, where the low fp16 piece turns subnormal.  Per-sample error
+    against torch in float64, for the A-halo gather (forward form), its adjoint (dgrad form), the 3x3 halo weight
+    gradient and the split-once 4x4 stride-2 weight gradient.  What include/fcd_hip.h guarantees: full 22-bit operands
+    within 2^-15 of the maximum (per-sample error at the 1e-6 level), beyond that an absolute, not a relative bound --
+    at 2^-18 the small samples are still good to 1e-5."""
+    from fcd_amd import _lib as L, ops
+    bar = 1e-6 if log2_disparity <= 15 else 1e-5
+    N, C, H = 32, 128, 32
+    big = float(2 ** log2_disparity)
+    gen = torch.Generator().manual_seed(31)
+    g3 = ops.ConvGeom(C, C, 3, 1, 1)
+    wt = torch.randn(C, C, 3, 3, generator=gen) / (3 * C ** 0.5)
+    wd = wt.to(dev)
+    wa = ops.absmax(wd)
+    x = torch.randn(N, C, H, H, generator=gen)
+    x[5] *= big
+    xd = to_nhwc(x, g3.IP).to(dev)
+    xa = ops.absmax(xd)
+
+    def per_sample(got, ref):
+        return [relerr(got[i], ref[i]) for i in range(got.shape[0])]
+
+    # gather, forward form
+    d = ops.set_amax(g3.fwd_desc(N, H, H, precision=L.PREC_F16X2), xa, wa)
+    got = from_nhwc(ops.conv_gather(d, xd, ops.pack_weight_fwd_h2(wd, g3, wa)).cpu(), C).double()
+    assert L.load().fcd_last_conv_kernel().endswith(b"true, true, 2>")
+    e_f = per_sample(got, F.conv2d(x.double(), wt.double(), None, 1, 1))
+    # gather, adjoint form (data gradient)
+    d = ops.set_amax(g3.adj_desc(N, H, H, precision=L.PREC_F16X2), xa, wa)
+    got = from_nhwc(ops.conv_gather(d, xd, ops.pack_weight_adj_h2(wd, g3, wa)).cpu(), C).double()
+    e_a = per_sample(got, F.conv_transpose2d(x.double(), wt.double(), None, 1, 1))
+    print(f"disparity 2^{log2_disparity}: gather worst small-sample rel-err {max(e_f[:5] + e_f[6:]):.2e} (large sample "
+          f"{e_f[5]:.2e}); adjoint {max(e_a[:5] + e_a[6:]):.2e} ({e_a[5]:.2e})")
+    assert max(e_f) <= bar and max(e_a) <= bar, (e_f, e_a)
+    assert e_f[5] <= 1e-6 and e_a[5] <= 1e-6
+
+    # weight gradients: the sum over samples is dominated by the large one, so the small samples are also run ALONE
+    # with the maxima of the whole tensors attached -- their own contribution under the shared scale
+    small = [i for i in range(N) if i != 5][:12]
+    for name, geom, xin in (("wgrad3_halo", ops.ConvGeom(256, 256, 3, 1, 1), None), ("wgrad_x3p", ops.ConvGeom(C, C, 4, 2, 1), None)):
+        if geom.k == 3:                      # 256 channels, 8 x 32 images: the shape class wgrad3_halo_x3_kernel<2> takes
+            xin = torch.randn(N, 256, 8, 32, generator=gen)
+            gy = torch.randn(N, 256, 8, 32, generator=gen)
+        else:                                # 4x4 stride 2: input 64 x 64 -> gradient 32 x 32
+            xin = torch.randn(N, C, 2 * H, 2 * H, generator=gen)
+            gy = torch.randn(N, C, H, H, generator=gen)
+        xin[5] *= big
+        gd = to_nhwc(gy, geom.OP).to(dev)
+        ga = ops.absmax(gd)
+        xbd = to_nhwc(xin, geom.IP).to(dev)
+        xba = ops.absmax(xbd)
+        bh, bw = xin.shape[2], xin.shape[3]
+        dsc = ops.set_wgrad_amax(geom.wgrad_desc(N, bh, bw, precision=L.PREC_F16X2), ga, xba)
+        dw = ops.conv_wgrad(dsc, gd, xbd)
+        ref = torch.nn.grad.conv2d_weight(xin.double(), tuple(dw.shape), gy.double(), stride=geom.s, padding=geom.p)
+        e_all = relerr(dw.cpu(), ref)
+        ds = ops.set_wgrad_amax(geom.wgrad_desc(len(small), bh, bw, precision=L.PREC_F16X2), ga, xba)
+        dws = ops.conv_wgrad(ds, gd[small].contiguous(), xbd[small].contiguous())
+        refs = torch.nn.grad.conv2d_weight(xin[small].double(), tuple(dw.shape), gy[small].double(), stride=geom.s,
+                                           padding=geom.p)
+        e_small = relerr(dws.cpu(), refs)
+        print(f"  {name} ({L.load().fcd_last_conv_kernel().decode()}): all samples {e_all:.2e}, small samples under the "
+              f"shared scale {e_small:.2e}")
+        assert e_all <= 1e-6 and e_small <= bar, (name, e_all, e_small)
+
+
+def test_f16x2_overflow_guard(dev):
+    """A max |.| that is too small for its tensor (stale slot, a producer that forgot it) must not turn into silent
+    Inf / NaN: every fp32x2 kernel raises the device's overflow word when a scaled operand passes 2^15, and
+    ops.check_overflow turns it into an error.  Correct maxima leave the word alone."""
+    from fcd_amd import _lib as L, ops
+    g = ops.ConvGeom(64, 64, 3, 1, 1)
+    gen = torch.Generator().manual_seed(33)
+    wt = torch.randn(64, 64, 3, 3, generator=gen) / 24.0
+    x = torch.randn(8, 64, 32, 32, generator=gen)
+    wd, xd = wt.to(dev), to_nhwc(x, g.IP).to(dev)
+    wa, xa = ops.absmax(wd), ops.absmax(xd)
+    ops.check_overflow(dev)                                # clean start
+    d = ops.set_amax(g.fwd_desc(8, 32, 32, precision=L.PREC_F16X2), xa, wa)
+    wp = ops.pack_weight_fwd_h2(wd, g, wa)
+    ops.conv_gather(d, xd, wp)
+    ops.check_overflow(dev)                                # correct maxima: nothing raised
+    # activation maximum 64 x too small (a stale slot): the gather kernel's halo split sees values up to 2^19
+    d_bad = ops.set_amax(g.fwd_desc(8, 32, 32, precision=L.PREC_F16X2), xa / 64.0, wa)
+    out = ops.conv_gather(d_bad, xd, wp)
+    with pytest.raises(RuntimeError, match="overflow guard"):
+        ops.check_overflow(dev)
+    ops.check_overflow(dev)                                # the poll cleared the word
+    assert not bool(torch.isfinite(out).all()) or True     # (the output itself may or may not hold Inf: the word is the signal)
+    # weight maximum too small: caught by the pack kernel
+    ops.pack_weight_fwd_h2(wd, g, wa / 64.0)
+    with pytest.raises(RuntimeError, match="overflow guard"):
+        ops.check_overflow(dev)
+    # weight gradient with a stale gradient maximum
+    gy = torch.randn(8, 64, 32, 32, generator=gen)
+    gd = to_nhwc(gy, g.OP).to(dev)
+    dw_desc = ops.set_wgrad_amax(g.wgrad_desc(8, 32, 32, precision=L.PREC_F16X2), ops.absmax(gd) / 64.0, xa)
+    ops.conv_wgrad(dw_desc, gd, xd)
+    with pytest.raises(RuntimeError, match="overflow guard"):
+        ops.check_overflow(dev)
+    # a NaN operand is not an overflow: it propagates into the result as it would in fp32, and the word stays clear
+    xn = xd.clone()
+    xn[0, 5, 5, 0] = float("nan")
+    outn = ops.conv_gather(d, xn, wp)
+    ops.check_overflow(dev)
+    assert bool(torch.isnan(outn[0, 5, 5]).any()) and bool(torch.isfinite(outn[1:]).all())
+    # and a solver polls it from train_step / state_dict
+    ops.conv_gather(d_bad, xd, wp)
+    from fcd_amd import FCDSolver
+    s = FCDSolver(None, c_dim=1, image_size=32, g_conv_dim=8, d_conv_dim=8, g_repeat_num=1, d_repeat_num=3,
+                  num_channels=10, batch_size=2, precision="fp32x2").to(dev)
+    with pytest.raises(RuntimeError, match="overflow guard"):
+        s.state_dict()
+    s.state_dict()

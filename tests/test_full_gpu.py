@@ -4,8 +4,8 @@ size-independent properties.  Inputs and weights are regenerated from the numpy-
 
 The reference's own fp32 step is ill-conditioned at this size (its fp32 gradients differ from its
 fp64 gradients by up to 3e-3 per tensor), so gradients are judged against
-the fp64 oracle: the HIP error may not exceed max(1e-4, 1.5 x the reference-fp32 error) in the default fp32x3
-mode (2.0 x for the exact-fp32 MFMA chains), norm-wise on two independent samples per tensor, plus an
+the fp64 oracle: the HIP error may not exceed max(1e-4, 1.25 x the reference-fp32 error) in the split-operand
+modes fp32x2 (the benchmarked default) and fp32x3 (2.0 x for the exact-fp32 MFMA chains), norm-wise on two independent samples per tensor, plus an
 element-wise bar (FACTORS below); the measured errors are written to
 gpurun_out/full_parity_{d,g}_{precision}.json (copies under profiles/).
 """
@@ -54,7 +54,9 @@ BIG = np.load(os.path.join(GOLD, "full_grad_samples.npz"))
 #     extreme-value statistic of a step with ReLU / LeakyReLU / L1 kinks: a single activation-mask flip moves a
 #     few elements by O(1) of their value in either fp32 evaluation (worst ratio 9.8, D features.1.0.weight).
 # The measured errors of every tensor are written to gpurun_out/full_parity_*.json.
-FACTORS = {"fp32x3": (1.5, 3.0), "fp32x2": (1.5, 3.0), "fp32": (2.0, 12.0)}
+# Round 3: the split-operand modes' bars tightened to what they need (worst measured ratios: 0.83 fp32x2 G step, 1.18
+# fp32x3 D step norm-wise; 2.0 element-wise): 1.25 and 2.5.
+FACTORS = {"fp32x3": (1.25, 2.5), "fp32x2": (1.25, 2.5), "fp32": (2.0, 12.0)}
 OUT_DIR = os.path.join(os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(__file__))), "gpurun_out")
 
 
@@ -74,7 +76,7 @@ def sample_errors(grad, tag, name, sc, which=""):
 
 def check_grads(net, tag, sc, prec):
     FACTOR, FACTOR_MAX = FACTORS[prec]
-    report, worst = {}, 0.0
+    report, worst, failures = {}, 0.0, []
     for name, p in net.named_parameters():
         entry = {}
         for which in ("", "2"):
@@ -82,13 +84,14 @@ def check_grads(net, tag, sc, prec):
             bar, bar_max = max(1e-4, FACTOR * eref), max(1e-4, FACTOR_MAX * eref_max)
             entry["sample" + (which or "1")] = {"hip": e, "ref_fp32": eref, "hip_maxabs": emax, "ref_fp32_maxabs": eref_max}
             worst = max(worst, e / bar, emax / bar_max)
-            if os.environ.get("FCD_PARITY_SURVEY"):
-                continue
-            assert e <= bar, (name, which, e, eref)
-            assert emax <= bar_max, (name, which, emax, eref_max)
+            if e > bar:
+                failures.append((name, which, "norm-wise", e, eref))
+            if emax > bar_max:
+                failures.append((name, which, "element-wise", emax, eref_max))
         n64 = sc[f"{tag}_grad_norm64"][name]
         nbar = max(1e-4, FACTOR * sc["ref_fp32_vs_fp64_grad_relerr"][tag][name])
-        assert abs(float(p.grad.double().norm()) - n64) <= nbar * n64, name
+        if abs(float(p.grad.double().norm()) - n64) > nbar * n64:
+            failures.append((name, "", "norm", float(p.grad.double().norm()), n64))
         report[name] = entry
     try:
         os.makedirs(OUT_DIR, exist_ok=True)
@@ -98,6 +101,8 @@ def check_grads(net, tag, sc, prec):
                        "errors_vs_fp64_oracle": report}, f, indent=1)
     except OSError:
         pass
+    # every tensor is measured and written out first; any miss still fails the test (no survey switch)
+    assert not failures, failures
     return worst
 
 
@@ -169,9 +174,10 @@ def test_full_bf16_losses(full):
         pass
 
 
-def test_full_masks_and_eval_forward(full):
+@pytest.mark.parametrize("prec", ["fp32", "fp32x2"])
+def test_full_masks_and_eval_forward(full, prec):
     sc, make, b, alpha = full
-    s = make()
+    s = make(prec)
     s.G.eval()
     with torch.no_grad():
         out = s.G(b[0], torch.zeros_like(b[2]))
@@ -184,11 +190,12 @@ def test_full_masks_and_eval_forward(full):
     assert abs(int(mask.sum()) - sc["mask_popcount"]) <= near + sc["diff_margin_count"]
 
 
-def test_full_properties(full):
+@pytest.mark.parametrize("prec", ["fp32", "fp32x2"])
+def test_full_properties(full, prec):
     """Size-independent properties: per-sample independence (what data parallelism relies on),
     determinism, invalid-pixel passthrough, and D's gradient linearity in grad_outputs."""
     sc, make, b, alpha = full
-    s = make()
+    s = make(prec)
     s.G.train()
     with torch.no_grad():
         o16 = s.G(b[0], b[2])
@@ -206,9 +213,10 @@ def test_full_properties(full):
     assert float((g3 - 3 * g1).abs().max()) <= 1e-5 * float(g1.abs().max())
 
 
-def test_full_train_steps_run_and_move_weights(full):
+@pytest.mark.parametrize("prec", ["fp32", "fp32x2"])
+def test_full_train_steps_run_and_move_weights(full, prec):
     sc, make, b, alpha = full
-    s = make()
+    s = make(prec)
     w0 = s.G.main[0].weight.detach().clone()
     d0 = s.D.conv1.weight.detach().clone()
     for _ in range(2):
@@ -219,7 +227,8 @@ def test_full_train_steps_run_and_move_weights(full):
     assert 1e-5 < float((s.D.conv1.weight - d0).abs().max()) < 1e-3
 
 
-def test_training_is_bitwise_reproducible(full):
+@pytest.mark.parametrize("prec", ["fp32x2", "fp32x3"])
+def test_training_is_bitwise_reproducible(full, prec):
     """Ten full-size training steps, twice, from the same state: identical bits in every weight and
     running statistic.  All reductions run in a fixed order and nothing in the training path uses
     floating-point atomics, so any difference would mean a race (LDS-DMA waits, stream ordering of
@@ -228,7 +237,7 @@ def test_training_is_bitwise_reproducible(full):
     sc, make, b, alpha = full
 
     def run():
-        s = make("fp32x3")
+        s = make(prec)
         s.alpha_override = alpha
         for _ in range(10):
             d_loss, g_loss = s.train_step(b, force_g=True)

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in fcd_hip.h but not exported"
     assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
     loaded = _lib.load()
-    assert loaded.fcd_abi_version() == 1
+    assert loaded.fcd_abi_version() == 2
 
 
 def test_descriptor_structs_match_header_layout():

@@ -101,6 +101,14 @@ def test_pool_rejects_bad_positions():
         pool.gather(torch.tensor([len(pool)]))
     with pytest.raises(RuntimeError):
         pool.gather(torch.tensor([0]), ret_mask=True)
+    # device-resident positions: no device-side assert (it would poison the process); the bad position is clamped for
+    # the gather and reported by check_positions()
+    out = pool.gather(torch.tensor([0, len(pool) + 3], device=pool.device))
+    assert out["image"].shape[0] == 2 and bool(torch.isfinite(out["image"]).all())
+    with pytest.raises(IndexError):
+        pool.check_positions()
+    pool.gather(torch.tensor([0, len(pool) - 1], device=pool.device))
+    pool.check_positions()          # in range: nothing raised, flag cleared
 
 
 def test_loader_feeds_train_and_validation_steps():

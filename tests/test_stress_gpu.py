@@ -53,7 +53,7 @@ def test_stress_config_properties(dev, mode):
     assert torch.equal(mask.cpu(), (diff.cpu() > 0.027).to(torch.uint8))
 
 
-@pytest.mark.parametrize("prec", [0, 2])
+@pytest.mark.parametrize("prec", [0, 2, 3])
 def test_operands_over_2gib(dev, prec):
     """Tensors beyond 2 GiB: every workgroup addresses a window of its own images with 32-bit lane offsets
     (VERDICT r1 item 8).  3x3 64 -> 64 at 256x256 is 16 MiB per image; 136 images = 2.125 GiB per operand.
@@ -67,36 +67,104 @@ def test_operands_over_2gib(dev, prec):
     gy = torch.randn(N, H, W, 64, device=dev, generator=gen)
     w = torch.randn(64, 64, 3, 3, device=dev, generator=gen) / 24.0
     assert x.numel() * 4 > (1 << 31)
-    d = g.fwd_desc(N, H, W, precision=prec)
-    wf = ops.pack_weight_fwd_x3(w, g) if ops.wants_split_weights(d) else ops.pack_weight_fwd(w, g)
+    # prec 3 (FCD_PREC_F16X2, the bench default): the maxima of the WHOLE tensors go with every descriptor, so that the
+    # three-image launches scale their operands exactly like the 136-image ones and the comparison stays bit for bit
+    xa, ga, wam = (ops.absmax(x), ops.absmax(gy), ops.absmax(w)) if prec == 3 else (None, None, None)
+
+    def conv_desc(dsc, amax):
+        return ops.set_amax(dsc, amax, wam) if prec == 3 else dsc
+
+    def packs(dsc, form):
+        fmt = ops.weight_format(dsc)
+        if fmt == 2:
+            return ops.pack_weight_fwd_h2(w, g, wam) if form == "fwd" else ops.pack_weight_adj_h2(w, g, wam)
+        if fmt == 1:
+            return ops.pack_weight_fwd_x3(w, g) if form == "fwd" else ops.pack_weight_adj_x3(w, g)
+        return ops.pack_weight_fwd(w, g) if form == "fwd" else ops.pack_weight_adj(w, g)
+
+    d = conv_desc(g.fwd_desc(N, H, W, precision=prec), xa)
+    wf = packs(d, "fwd")
     out = ops.conv_gather(d, x, wf)
-    d3 = g.fwd_desc(3, H, W, precision=prec)
+    d3 = conv_desc(g.fwd_desc(3, H, W, precision=prec), xa)
     out3 = ops.conv_gather(d3, x[-3:].contiguous(), wf)
     assert torch.equal(out[-3:], out3)
     assert float(out3.abs().max()) > 0.1
     # adjoint form (data gradient) on the same operands
-    da = g.adj_desc(N, H, W, precision=prec)
-    wa = ops.pack_weight_adj_x3(w, g) if ops.wants_split_weights(da) else ops.pack_weight_adj(w, g)
+    da = conv_desc(g.adj_desc(N, H, W, precision=prec), ga)
+    wa = packs(da, "adj")
     gx = ops.conv_gather(da, gy, wa)
-    gx3 = ops.conv_gather(g.adj_desc(3, H, W, precision=prec), gy[-3:].contiguous(), wa)
+    gx3 = ops.conv_gather(conv_desc(g.adj_desc(3, H, W, precision=prec), ga), gy[-3:].contiguous(), wa)
     assert torch.equal(gx[-3:], gx3)
     del out, gx
     # weight gradient: K axis = all 136 x 65536 pixels
-    dw = ops.conv_wgrad(g.wgrad_desc(N, H, W, precision=prec), gy, x)
+    def wdesc(n):
+        dsc = g.wgrad_desc(n, H, W, precision=prec)
+        return ops.set_wgrad_amax(dsc, ga, xa) if prec == 3 else dsc
+
+    dw = ops.conv_wgrad(wdesc(N), gy, x)
     h = N // 2
-    dh = g.wgrad_desc(h, H, W, precision=prec)
+    dh = wdesc(h)
     dw2 = ops.conv_wgrad(dh, gy[:h].contiguous(), x[:h].contiguous()).double() + \
         ops.conv_wgrad(dh, gy[h:].contiguous(), x[h:].contiguous()).double()
     assert float((dw.double() - dw2).norm() / dw2.norm()) <= 1e-5
 
 
-def test_stress_batch_64_paired(dev):
+@pytest.mark.parametrize("shape", [(128, 128, 1056, 64, 64), (256, 256, 2176, 32, 32)])
+def test_f16x2_halo_kernels_over_2gib(dev, shape):
+    """The fp32x2 kernels that the benchmark's hot layers run -- the two-plane A-halo gather (forward and adjoint form;
+    image width 64 and 32) and wgrad3_halo_x3_kernel<2> (width 32) -- on operands beyond 2 GiB: the last images must
+    come out bit for bit as when they are convolved on their own under the same scales, the weight gradient over all
+    images must equal the sum over the two halves, and a sample of output pixels past the 2 GiB mark is checked
+    against torch in float64 (parity at this size is otherwise unpinned: the CPU needs minutes for the whole tensor)."""
+    import torch.nn.functional as F
+    from fcd_amd import _lib as L, ops
+    O, I, N, H, W = shape
+    g = ops.ConvGeom(O, I, 3, 1, 1)
+    gen = torch.Generator(device=dev).manual_seed(13)
+    x = torch.randn(N, H, W, I, device=dev, generator=gen)
+    gy = torch.randn(N, H, W, O, device=dev, generator=gen)
+    w = torch.randn(O, I, 3, 3, device=dev, generator=gen) / (3 * I ** 0.5)
+    assert x.numel() * 4 > (1 << 31)
+    xa, ga, wam = ops.absmax(x), ops.absmax(gy), ops.absmax(w)
+    d = ops.set_amax(g.fwd_desc(N, H, W, precision=L.PREC_F16X2), xa, wam)
+    assert ops.weight_format(d) == 2
+    wf = ops.pack_weight_fwd_h2(w, g, wam)
+    out = ops.conv_gather(d, x, wf)
+    assert L.load().fcd_last_conv_kernel().endswith(b"true, true, 2>")          # the A-halo form, two planes
+    tail = ops.conv_gather(ops.set_amax(g.fwd_desc(16, H, W, precision=L.PREC_F16X2), xa, wam), x[-16:].contiguous(), wf)
+    assert torch.equal(out[-16:], tail)
+    ref = F.conv2d(x[-2:].permute(0, 3, 1, 2).double().cpu(), w.double().cpu(), None, 1, 1).permute(0, 2, 3, 1)
+    assert float((out[-2:].double().cpu() - ref).norm() / ref.norm()) <= 1e-6
+    del out
+    da = ops.set_amax(g.adj_desc(N, H, W, precision=L.PREC_F16X2), ga, wam)
+    wadj = ops.pack_weight_adj_h2(w, g, wam)
+    gx = ops.conv_gather(da, gy, wadj)
+    assert L.load().fcd_last_conv_kernel().endswith(b"true, true, 2>")
+    tail = ops.conv_gather(ops.set_amax(g.adj_desc(16, H, W, precision=L.PREC_F16X2), ga, wam), gy[-16:].contiguous(), wadj)
+    assert torch.equal(gx[-16:], tail)
+    del gx, tail
+
+    def wdesc(n):
+        return ops.set_wgrad_amax(g.wgrad_desc(n, H, W, precision=L.PREC_F16X2), ga, xa)
+
+    dw = ops.conv_wgrad(wdesc(N), gy, x)
+    kernel = L.load().fcd_last_conv_kernel()
+    assert kernel == (b"wgrad3_halo_x3_kernel<2>" if W == 32 else b"conv_wgrad_x3p_kernel<128, 4, 2, 2>"), kernel
+    h = N // 2
+    dw2 = ops.conv_wgrad(wdesc(h), gy[:h].contiguous(), x[:h].contiguous()).double() + \
+        ops.conv_wgrad(wdesc(h), gy[h:].contiguous(), x[h:].contiguous()).double()
+    assert float((dw.double() - dw2).norm() / dw2.norm()) <= 1e-5
+    ops.check_overflow(dev)
+
+
+@pytest.mark.parametrize("mode", ["fp32x3", "fp32x2"])
+def test_stress_batch_64_paired(dev, mode):
     """configs[4] at 64 samples per GPU with the paired calls on (128-image batches inside the step: every
     full-resolution activation is 4 GiB): finite losses, weights move, per-sample independence holds."""
     from fcd_amd import FCDSolver
     from fcd_amd.synth import synth_batch
     torch.manual_seed(5)
-    s = FCDSolver(None, image_size=256, g_conv_dim=128, d_conv_dim=128, batch_size=64, precision="fp32x3").to(dev)
+    s = FCDSolver(None, image_size=256, g_conv_dim=128, d_conv_dim=128, batch_size=64, precision=mode).to(dev)
     batch, _ = synth_batch(64, 256, 10, seed=4)
     b = tuple(t.to(dev) for t in batch)
     assert s.pair_d_calls and s.pair_g_calls and s._pair_fits(b[0], s.g_conv_dim)
