@@ -593,6 +593,28 @@ def main():
         res["roofline"] = dominant_kernel_roofline(args.precision, dev,
                                                    timer.mean_us("dominant") if timer.pairs else None,
                                                    timer.count("dominant"), symbol=timer.total() if timer.pairs else None)
+        if world == 1:
+            # the same step with the reference's literal call sequence: G(x_real, c_trg) computed in the D step AND
+            # again in the G step, and the D(x_reconst_id) forward whose outputs nothing reads (fcd_solver.py:291, 316, 358)
+            solver.share_generator_forward = solver.skip_unused_d_forward = False
+            for _ in range(5):
+                step()
+            torch.cuda.synchronize()
+            tq = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+            dtq = time.perf_counter() - tq
+            solver.share_generator_forward = solver.skip_unused_d_forward = True
+            res["reference_call_sequence"] = {
+                "value": round(BASE["batch"] * args.steps / dtq, 2), "unit": "images/sec",
+                "ms_per_step": round(dtq / args.steps * 1e3, 3),
+                "note": "`value` shares one generator call between the D step and the G step (the reference computes "
+                        "G(x_real, c_trg) twice per step with identical weights and inputs) and leaves out a discriminator "
+                        "forward whose outputs the reference discards; same losses, gradients, weights and running "
+                        "statistics (tests/test_step_gpu.py::test_shared_generator_forward_equals_reference_sequence). "
+                        "This field times the step with both switched off: 13 generator and 15 discriminator passes "
+                        "as in BASELINE.md's FLOP convention; `value` executes 12 and 14"}
         if args.precision in ("fp32x3", "fp32x2") and world == 1:
             # the same step with exact-fp32 MFMA everywhere (v_mfma_f32_32x32x2_f32), for reference
             solver.set_precision("fp32")

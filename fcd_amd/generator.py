@@ -288,6 +288,7 @@ class Generator(nn.Module):
         self._plan = plan
         self._wmax = WeightMaxima(ly.conv for ly in plan)
         self._groups = 1
+        self._repeat_first = 0        # extra running-statistics updates with the first sample group (repeat_first_group)
         self._grad_hook = None        # parallel.BucketedReducer while a data-parallel G step runs
         self._grad_mode = True        # torch.is_grad_enabled() at the last forward call
         self._stats_epoch = 0         # bumped whenever a kernel rewrites the running statistics
@@ -305,6 +306,20 @@ class Generator(nn.Module):
             yield
         finally:
             self._groups = prev
+
+    @contextlib.contextmanager
+    def repeat_first_group(self, times: int = 1):
+        """Inside this context (together with :meth:`sample_groups`) a forward call also stands for ``times`` EARLIER
+        reference calls on its first sample group: the tracked running statistics receive ``times`` extra momentum
+        updates with that group's batch statistics before the per-group updates.  The solver uses it when the D step
+        and the G step of one training step share the generator call ``G(x_real, c_trg)`` (``fcd_solver.py:291, 316``:
+        the same inputs through the same weights, computed twice by the reference): outputs are shared, and the
+        running statistics still see every reference call, in the reference's order."""
+        prev, self._repeat_first = self._repeat_first, int(times)
+        try:
+            yield
+        finally:
+            self._repeat_first = prev
 
     # parameters in plan order: (conv.weight, norm.weight, norm.bias)*
     def _flat_params(self):
@@ -419,6 +434,11 @@ class _GeneratorFn(torch.autograd.Function):
             saved.append((z, mean, rstd, use_running))
             acts.append(y)
         for items in running.values():
+            if mod._repeat_first:
+                nfirst = n // mod._groups
+                first = [(rm, rv, mean[:nfirst], varu[:nfirst]) for rm, rv, mean, varu in items]
+                for _ in range(mod._repeat_first):
+                    ops.instnorm_update_running_batch(first, groups=1)
             ops.instnorm_update_running_batch(items, groups=mod._groups)
         if running:
             mod._stats_epoch += 1      # raw-pointer writes do not bump tensor versions: folded() keys on this

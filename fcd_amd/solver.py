@@ -186,6 +186,11 @@ class FCDSolver(nn.Module):
         self._scheds = None
         self.pair_g_calls = True                    # G step: the four generator calls as two paired-batch calls
         self.pair_d_calls = True                    # D step: D(x_real) and D(x_fake) as one paired-batch call
+        # train_step only (training_step called by hand keeps the reference's own sequence):
+        self.share_generator_forward = True         # the D step's G(x_real, c_trg) IS the G step's first generator call
+        self.skip_unused_d_forward = True           # D(x_reconst_id) (reference :358) feeds nothing unless use_feats
+        self._shared_fake = None
+        self._in_train_step = False
         self._pending = None
         self._val_cm = None
         self.freeze_host_objects = True             # gc.freeze() after the first train_step (see there)
@@ -293,7 +298,7 @@ class FCDSolver(nn.Module):
             if self.pair_d_calls and self._pair_fits(x_real, self.d_conv_dim // 4):
                 # D(x_real) and D(x_fake) as one call on the paired batch (D has no cross-sample coupling)
                 nb = x_real.size(0)
-                x_fake = self.G(x_real, c_trg)
+                x_fake = self._shared_fake[:nb] if self._shared_fake is not None else self.G(x_real, c_trg)
                 src2, cls2, _ = self.D(torch.cat([x_real, x_fake.detach()]))
                 d_loss_real = losses.mean_scaled(src2[:nb], -1.0)
                 d_loss_cls = self.classification_loss(cls2[:nb], label_org, self.dataset)
@@ -303,7 +308,7 @@ class FCDSolver(nn.Module):
                 d_loss_real = losses.mean_scaled(out_src, -1.0)
                 d_loss_cls = self.classification_loss(out_cls, label_org, self.dataset)
 
-                x_fake = self.G(x_real, c_trg)
+                x_fake = self._shared_fake[:x_real.size(0)] if self._shared_fake is not None else self.G(x_real, c_trg)
                 out_src, out_cls, _ = self.D(x_fake.detach())
                 d_loss_fake = losses.mean_scaled(out_src, 1.0)
 
@@ -328,15 +333,20 @@ class FCDSolver(nn.Module):
                     # every loss term are per sample; Generator.sample_groups keeps the running-statistics
                     # updates in the reference's order), and every launch-bound kernel runs half as often.
                     nb = x_real.size(0)
-                    with self.G.sample_groups(2):
-                        fake2 = self.G(torch.cat([x_real, x_real]), torch.cat([c_trg, c_org]))
+                    if self._shared_fake is not None:
+                        fake2, self._shared_fake = self._shared_fake, None      # made by train_step before the D step
+                    else:
+                        with self.G.sample_groups(2):
+                            fake2 = self.G(torch.cat([x_real, x_real]), torch.cat([c_trg, c_org]))
                     x_fake, x_fake_id = fake2[:nb], fake2[nb:]
-                    src2, cls2, feats2 = self.D(fake2)
-                    out_src, out_cls = src2[:nb], cls2[:nb]
-                    out_src_id, out_cls_id, x_fake_id_feats = src2[nb:], cls2[nb:], [f[nb:] for f in feats2]
+                    # (the reconstruction call first: it does not need D, so a deferred D update -- data parallel: D's
+                    #  gradient all-reduce -- keeps running beside it; D's forward pre-hook below waits for it)
                     with self.G.sample_groups(2):
                         rec2 = self.G(fake2, torch.cat([c_org, c_org]))
                     x_reconst, x_reconst_id = rec2[:nb], rec2[nb:]
+                    src2, cls2, feats2 = self.D(fake2)
+                    out_src, out_cls = src2[:nb], cls2[:nb]
+                    out_src_id, out_cls_id, x_fake_id_feats = src2[nb:], cls2[nb:], [f[nb:] for f in feats2]
                 else:
                     x_fake = self.G(x_real, c_trg)
                     out_src, out_cls, _ = self.D(x_fake)
@@ -353,7 +363,10 @@ class FCDSolver(nn.Module):
 
                 g_loss_rec = losses.l1_mean(x_real, x_reconst)
 
-                _, _, x_reconst_id_feats = self.D(x_reconst_id)    # reference :358
+                if self.use_feats or not self._in_train_step or not self.skip_unused_d_forward:
+                    _, _, x_reconst_id_feats = self.D(x_reconst_id)    # reference :358
+                # (else: the reference computes this forward and drops its outputs -- only use_feats reads them, D has
+                #  no buffers, nothing requires its graph: a dead call, left out by train_step)
                 g_loss_rec_id = losses.l1_mean(x_real, x_reconst_id)
 
                 if self.use_feats:
@@ -482,8 +495,25 @@ class FCDSolver(nn.Module):
         batch = tuple(t.to(self.device) for t in batch)
         if force_g:
             self.global_step = self.n_critic - 1 + (self.global_step // self.n_critic) * self.n_critic
-        d_loss = self._run_optimizer(batch, batch_idx, 0, True)
-        g_loss = self._run_optimizer(batch, batch_idx, 1, (self.global_step + 1) % self.n_critic == 0)
+        g_runs = (self.global_step + 1) % self.n_critic == 0
+        x_real, c_org, c_trg = batch[0], batch[1], batch[2]
+        self._in_train_step = True
+        try:
+            if (self.share_generator_forward and g_runs and self.G.training and self.pair_g_calls
+                    and self._pair_fits(x_real, self.g_conv_dim)):
+                # The reference calls G(x_real, c_trg) in the D step (fcd_solver.py:291, no graph) and again as the
+                # G step's first call (:316) -- the same inputs through the same weights (G is only updated at the end
+                # of the G step).  Here the call is made ONCE, as half of the G step's first paired call, with its graph
+                # kept for the G step; the D step takes the detached output.  repeat_first_group gives the tracked
+                # running statistics the D step's update as well, so they see five reference calls per step.
+                self.G.requires_grad_(True)
+                with self.G.sample_groups(2), self.G.repeat_first_group(1):
+                    self._shared_fake = self.G(torch.cat([x_real, x_real]), torch.cat([c_trg, c_org]))
+            d_loss = self._run_optimizer(batch, batch_idx, 0, True)
+            g_loss = self._run_optimizer(batch, batch_idx, 1, g_runs)
+        finally:
+            self._in_train_step = False
+            self._shared_fake = None
         self._flush_pending()          # no G update this step: nothing used D in between
         self.global_step += 1
         if self.precision == "fp32x2" and (self.global_step == 1 or self.global_step % self.overflow_check_every == 0):

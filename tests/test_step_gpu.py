@@ -205,6 +205,45 @@ def test_two_train_steps_match_oracle(dev, tiny):
     assert worst <= 5e-3
 
 
+@pytest.mark.parametrize("prec", ["fp32", "fp32x2"])
+def test_shared_generator_forward_equals_reference_sequence(dev, tiny, prec):
+    """train_step makes the generator call G(x_real, c_trg), which the reference computes twice per step with the same
+    weights (fcd_solver.py:291 in the D step, :316 in the G step), once, and leaves out D(x_reconst_id) (:358), whose
+    outputs nothing reads unless use_feats.  Against the reference's own call sequence (both switches off): the same
+    losses, weights and running statistics after three steps, up to the rounding of one 16-sample call against half of
+    a 32-sample call (running statistics: every reference call still counts -- five momentum updates per step)."""
+    z, sc = tiny
+    states = {}
+    for share in (True, False):
+        s = build(z, sc["cfg"], dev)
+        s.set_precision(prec)
+        s.share_generator_forward = share
+        s.skip_unused_d_forward = share
+        s.alpha_override = torch.from_numpy(z["alpha"])
+        b = batch_of(z, dev)
+        for _ in range(3):
+            s.train_step(b, force_g=True)
+        torch.cuda.synchronize()
+        assert s._shared_fake is None
+        states[share] = ({k: v.detach().clone() for k, v in s.state_dict().items()},
+                         {k: float(v) for k, v in s.loss_dict.items()})
+    (sd1, l1), (sd0, l0) = states[True], states[False]
+    for k in l0:
+        assert abs(l1[k] - l0[k]) <= 1e-4 * max(1.0, abs(l0[k])), (k, l1[k], l0[k])
+    worst, worst_stats = 0.0, 0.0
+    for k, v in sd0.items():
+        if not v.is_floating_point():
+            continue
+        e = relerr(sd1[k], v)
+        if "running" in k:
+            worst_stats = max(worst_stats, e)
+        else:
+            worst = max(worst, e)
+    print("shared forward vs reference sequence:", prec, "weights", worst, "running statistics", worst_stats)
+    assert worst_stats <= 1e-5            # an update more or less would show at the 1e-1 level
+    assert worst <= 5e-3                  # Adam's first steps are ~lr * sign(g): rounding-level gradients may flip
+
+
 def test_arena_gradients_match_fixtures(dev, tiny):
     """Same D-step gradients when the backward kernels accumulate straight into the gradient
     arena (the training path) instead of going through autograd (the other tests)."""

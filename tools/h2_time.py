@@ -6,8 +6,9 @@ from fcd_amd import ops, _lib as L
 prec = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 dev = torch.device('cuda:0')
 g = ops.ConvGeom(256, 256, 3, 1, 1)
-x = torch.randn(32, 32, 32, 256, device=dev); wt = torch.randn(256, 256, 3, 3, device=dev) / 48
-d = g.fwd_desc(32, 32, 32, precision=prec)
+NS = int(os.environ.get("H2_N", "32"))
+x = torch.randn(NS, 32, 32, 256, device=dev); wt = torch.randn(256, 256, 3, 3, device=dev) / 48
+d = g.fwd_desc(NS, 32, 32, precision=prec)
 fmt = ops.weight_format(d)
 if fmt == 2:
     wa = ops.absmax(wt); ops.set_amax(d, ops.absmax(x), wa); wf = ops.pack_weight_fwd_h2(wt, g, wa)
