@@ -529,6 +529,33 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         early = [r[1].fired_early for _, r in sorted(solver._reducers.items())]
+        spans = {"DG"[k]: r[1].describe() for k, r in sorted(solver._reducers.items())}
+        # What the all-reduce costs this run (rank 0's view; after the timed region): two short windows of the same
+        # loop, gradient spans sent from inside backward (the default) and only after it, with HIP events around every
+        # wait for a collective -- `allreduce_exposed_ms` is the part of the gradient exchange that compute did not hide
+        overlap = {}
+        nw = max(3, min(10, args.steps))
+        for mode in ("on", "off"):
+            solver.bucket_overlap = mode == "on"
+            solver.grad_sync.timing = []
+            step()
+            torch.cuda.synchronize()
+            dist.barrier()
+            solver.grad_sync.exposed_ms()
+            tw = time.perf_counter()
+            for _ in range(nw):
+                step()
+            torch.cuda.synchronize()
+            dist.barrier()
+            dtw = time.perf_counter() - tw
+            ex = solver.grad_sync.exposed_ms()
+            # per step: D's wait and G's wait (one finish each per step)
+            overlap[mode] = {"ms_per_step": round(dtw / nw * 1e3, 3),
+                             "allreduce_exposed_ms": {k: v["stream_wait_ms"] for k, v in sorted(ex.items())},
+                             "allreduce_host_ms": {k: v["host_ms"] for k, v in sorted(ex.items())},
+                             "allreduce_mbytes": {k: round(v["bytes"] / 1e6, 1) for k, v in sorted(ex.items())}}
+        solver.bucket_overlap = True
+        solver.grad_sync.timing = None
         dist_info = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
                      "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if args.backend == "nccl" else None,
                      "grad_allreduce": "bucketed, issued from inside the last backward pass of each network "
@@ -536,6 +563,9 @@ def main():
                                        "behind the generator forwards of the G step)",
                      "spans_sent_from_inside_backward_last_step": {"D": early[0] if early else 0,
                                                                    "G": early[1] if len(early) > 1 else 0},
+                     "spans": spans,
+                     "allreduce_exposed_ms": overlap["on"]["allreduce_exposed_ms"],
+                     "bucket_overlap": overlap,
                      "ranks_per_visible_gpu": -(-world // max(1, ndev))}
 
     if rank == 0:

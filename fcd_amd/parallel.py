@@ -33,6 +33,11 @@ class GradSync:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self._flat = {}
+        # diagnostics (bench.py, the first real multi-GPU run): with `timing` set to a list, every finish() appends
+        # (tag, host seconds spent inside finish, (event before, event after) on the current stream or None, bytes):
+        # the event pair brackets exactly the stream's wait for the collectives -- the all-reduce time that backward
+        # and the next forward did NOT hide
+        self.timing = None
 
     def allreduce(self, params: List[torch.Tensor]) -> None:
         """Average ``p.grad`` over ranks, in place."""
@@ -83,17 +88,48 @@ class GradSync:
             work.append((dist.all_reduce(t, op=op, group=self.group, async_op=True), v, t, op))
         return work
 
-    def finish(self, handle) -> None:
+    def finish(self, handle, tag: str = "") -> None:
         """Make the current stream wait for the collectives of ``handle``."""
+        rec = self.timing is not None and bool(handle)
+        ev = None
+        if rec:
+            import time
+            t0 = time.perf_counter()
+            if handle[0][1].is_cuda:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
         for w, v, t, op in handle:
             w.wait()
             if op == dist.ReduceOp.SUM:
                 t.div_(self.world)
             if t is not v:
                 v.copy_(t)
+        if rec:
+            if ev is not None:
+                ev[1].record()
+            self.timing.append((tag, time.perf_counter() - t0, ev, sum(v.numel() * 4 for _, v, _, _ in handle)))
 
-    def allreduce_flat(self, flat: torch.Tensor) -> None:
-        self.finish(self.allreduce_flat_async(flat))
+    def exposed_ms(self):
+        """Per tag: mean milliseconds per finish() that the compute stream waited for gradient all-reduces (HIP events
+        around the wait; host wall time where the tensors live on the CPU) and the bytes per finish; clears the
+        record.  Call after a synchronisation."""
+        out = {}
+        for tag, host_s, ev, nbytes in self.timing or []:
+            ms = ev[0].elapsed_time(ev[1]) if ev is not None else host_s * 1e3
+            o = out.setdefault(tag, {"calls": 0, "stream_wait_ms": 0.0, "host_ms": 0.0, "bytes": 0})
+            o["calls"] += 1
+            o["stream_wait_ms"] += ms
+            o["host_ms"] += host_s * 1e3
+            o["bytes"] = nbytes
+        for o in out.values():
+            o["stream_wait_ms"] = round(o["stream_wait_ms"] / o["calls"], 3)
+            o["host_ms"] = round(o["host_ms"] / o["calls"], 3)
+        if self.timing is not None:
+            self.timing.clear()
+        return out
+
+    def allreduce_flat(self, flat: torch.Tensor, tag: str = "") -> None:
+        self.finish(self.allreduce_flat_async(flat), tag)
 
     def bucketed(self, arena, bucket_mb: Optional[float] = None) -> "BucketedReducer":
         """An overlapped reducer for one gradient arena (see :class:`BucketedReducer`)."""
@@ -227,6 +263,17 @@ class BucketedReducer:
         if self.missing[si] == 0 and not self.fired[si]:
             self._fire(si)
             self.fired_early += 1
+
+    def describe(self):
+        """Span layout for a benchmark line: bytes per span in the order they complete (end of the arena first), the
+        parameters in each, and how many went out from inside backward in the last step."""
+        names = {}
+        for i, p in enumerate(self.arena.params):
+            names.setdefault(self.span_of[i], []).append(i)
+        return {"spans_mb": [round((hi - lo) * 4 / (1 << 20), 2) for lo, hi in self.spans],
+                "params_per_span": [len(names.get(si, [])) for si in range(len(self.spans))],
+                "piece_mb": round(self.bucket_elems * 4 / (1 << 20), 2),
+                "sent_from_inside_backward_last_step": self.fired_early}
 
     def finish_rest(self):
         """After backward has returned: reduce the spans that were not sent from inside it."""

@@ -431,7 +431,7 @@ class FCDSolver(nn.Module):
             return
         handle, opt, step = self._pending
         self._pending = None
-        self.grad_sync.finish(handle)
+        self.grad_sync.finish(handle, "D")
         if step:
             opt.step()
         opt.arena.zero_grad()
@@ -474,9 +474,9 @@ class FCDSolver(nn.Module):
                         self._pending = (handle, opt, step)
                         return loss
                     if handle is not None:
-                        self.grad_sync.finish(handle)
+                        self.grad_sync.finish(handle, "DG"[optimizer_idx])
                     elif arena is not None:
-                        self.grad_sync.allreduce_flat(arena.grad)
+                        self.grad_sync.allreduce_flat(arena.grad, "DG"[optimizer_idx])
                     else:
                         self.grad_sync.allreduce([p for p in mine.parameters() if p.grad is not None])
                 if step:

@@ -47,3 +47,13 @@ def test_bench_starts_its_own_ranks(dev):
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["config"]["world_size"] == 2 and res["config"]["global_batch"] == 32
     assert res["value"] > 0
+    # the fields that make the first real multi-GPU run diagnose itself: span layout, the exposed (un-hidden) wait for
+    # the gradient all-reduce per network, and the same loop with the sends from inside backward switched off
+    cfg = res["config"]
+    assert set(cfg["spans"]) == {"D", "G"} and sum(cfg["spans"]["D"]["spans_mb"]) > 170 and sum(cfg["spans"]["G"]["spans_mb"]) > 32
+    assert max(cfg["spans"]["D"]["spans_mb"]) <= 135 and cfg["spans"]["D"]["piece_mb"] == 64.0
+    assert set(cfg["allreduce_exposed_ms"]) == {"D", "G"} and all(v >= 0 for v in cfg["allreduce_exposed_ms"].values())
+    for mode in ("on", "off"):
+        assert cfg["bucket_overlap"][mode]["ms_per_step"] > 0
+        assert abs(cfg["bucket_overlap"][mode]["allreduce_mbytes"]["D"] - 178.9) < 1.0
+    assert cfg["spans"]["D"]["sent_from_inside_backward_last_step"] >= 1          # (described after the timed region: overlap on)
