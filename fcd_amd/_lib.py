@@ -22,6 +22,8 @@ PREC_F32 = 0
 PREC_BF16 = 1
 PREC_BF16X3 = 2
 PREC_F16X2 = 3     # fp16 x 2 pieces on the 3x3 A-halo layers, BF16X3 elsewhere
+PREC_F16 = 4       # FCD_PREC_F16: the same kernels and operands, high fp16 piece only (one MFMA per product group)
+F16_FAMILY = (PREC_F16X2, PREC_F16)   # precisions whose convolutions take the scaled fp16 operands (maxima attached)
 
 c_float_p = C.c_void_p  # device pointers travel as opaque addresses
 

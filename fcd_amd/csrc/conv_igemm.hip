@@ -42,6 +42,7 @@ struct GatherArgs {
   unsigned* out_amax;    // optional: max |out| of this launch into FCD_AMAX_SLOTS per-block slots (pre-split kernels, no split-K)
   int out_amax_in_kernel; // host side: the launched kernel records out_amax itself (else the entry point runs fcd_absmax)
   unsigned* ovf;          // FCD_PREC_F16X2: the caller's sticky overflow word (fcd_set_overflow_flag) or NULL
+  int onep;               // host side: FCD_PREC_F16 -- the one-piece (NP = 1) instance of the two-plane kernels
 };
 
 __device__ __forceinline__ float epilogue_value(float v, int co, long o, const GatherArgs& p) {
@@ -232,6 +233,22 @@ __device__ __forceinline__ void split2_f16(const u32x4 v, float s, uint2& h, uin
   l.y = cvt_pk_f16(f2 - a2, f3 - a3);
 }
 
+// FCD_PREC_F16 (the reduced-precision variant; NP == 1 in the kernels below): the high piece alone, h = fp16(s x) -- one
+// fp16 MFMA per product group, 11 significant bits per operand (bf16 has 8), same scales, same overflow guard
+__device__ __forceinline__ void cvt4_f16(const u32x4 v, float s, uint2& h, float& om) {
+  const float f0 = __uint_as_float(v.x) * s, f1 = __uint_as_float(v.y) * s, f2 = __uint_as_float(v.z) * s, f3 = __uint_as_float(v.w) * s;
+  om = fmaxf(fmaxf(om, fabsf(f0)), fabsf(f1));
+  om = fmaxf(fmaxf(om, fabsf(f2)), fabsf(f3));
+  h.x = cvt_pk_f16(f0, f1);
+  h.y = cvt_pk_f16(f2, f3);
+}
+__device__ __forceinline__ void cvt8_f16(const f32x8 f, float s, bf16x8_t& h, float& om) {
+  uint2 h0, h1;
+  cvt4_f16(u32x4{__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3])}, s, h0, om);
+  cvt4_f16(u32x4{__float_as_uint(f[4]), __float_as_uint(f[5]), __float_as_uint(f[6]), __float_as_uint(f[7])}, s, h1, om);
+  h = __builtin_bit_cast(bf16x8_t, u32x4{h0.x, h0.y, h1.x, h1.y});
+}
+
 // eight fp32 values -> two fp16x8 pieces of s * v, in the bf16x8_t register type the fragment structs use
 __device__ __forceinline__ void split2x8(const f32x8 f, float s, bf16x8_t& h, bf16x8_t& l, float& om) {
   uint2 h0, l0, h1, l1;
@@ -337,7 +354,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
   static_assert(!BPRE || (PREC == FCD_PREC_BF16X3 && BN % 16 == 0 && !N16), "BPRE shape");
   // BPRE: a B row is 3 planes x 4 chunks (32 bf16 each); one DMA instruction ("unit") covers 16 rows of
   // a plane; units past 3*BN/16 (BN = 64: 12 units on 8 waves) are all-out-of-range dummies
-  static_assert(NP == 3 || (NP == 2 && BPRE), "two planes (fp16 x 2): pre-split weights only");
+  static_assert(NP == 3 || ((NP == 2 || NP == 1) && BPRE), "fp16 planes (two: FCD_PREC_F16X2, one: FCD_PREC_F16): pre-split weights only");
   constexpr int BUNITS = NP * BN / 16;
   constexpr int AL = AH ? 0 : BM / RPI, BL = BPRE ? (BUNITS + NW - 1) / NW : BN / RPI;   // DMA instructions per wave per K-tile
   constexpr int AOFF = AH ? 0 : BM * 8;                            // float4 chunks of a stage's activation part
@@ -531,7 +548,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
     // split that runs under the second step's MFMAs.
     struct Pieces { bf16x8_t ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN]; };
     float a_scale = 1.f, om = 0.f;         // om: max |scaled activation| this thread split (ovf_report)
-    if constexpr (NP == 2) a_scale = pow2_scale(p.a_amax);
+    if constexpr (NP <= 2) a_scale = pow2_scale(p.a_amax);
     // ---- AH: halo geometry, the staged next slice, the planes
     const int W2 = p.GW + 2, APX = (BM / p.GW + 2) * W2, PB = APX * 64;      // halo row pitch, halo pixels, plane bytes
     const int ah_y0 = (tm * BM - n0 * ghw) / p.GW;                          // first output row of this tile in its image
@@ -566,6 +583,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
         if (hp >= APX) continue;
         unsigned char* dst = Apl + hp * 64 + (((c4 >> 1) ^ ((hp >> 2) & 3)) << 4) + 8 * (c4 & 1);
         const u32x4 v = hst[j];
+        if constexpr (NP == 1) {
+          uint2 h2;
+          cvt4_f16(v, a_scale, h2, om);
+          *reinterpret_cast<uint2*>(dst) = h2;
+          continue;
+        }
         if constexpr (NP == 2) {
           uint2 h2, l2;
           split2_f16(v, a_scale, h2, l2, om);
@@ -597,11 +620,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
           const unsigned char* a = Apl + hp * 64 + (((2 * s2 + lh) ^ ((hp >> 2) & 3)) << 4);
           P.ah[mi] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(a));
           if constexpr (NP == 3) P.am[mi] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(a + PB));
-          P.al[mi] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(a + (NP - 1) * PB));
+          if constexpr (NP >= 2) P.al[mi] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(a + (NP - 1) * PB));
         } else {
           const int r = wm * WTM + mi * 32 + lr, sw = (r >> 1) & 7;
           const float4 lo = As[r * 8 + (c0 ^ sw)], hi = As[r * 8 + ((c0 + 1) ^ sw)];
-          if constexpr (NP == 2) split2x8(f32x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w}, a_scale, P.ah[mi], P.al[mi], om);
+          if constexpr (NP == 1) cvt8_f16(f32x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w}, a_scale, P.ah[mi], om);
+          else if constexpr (NP == 2) split2x8(f32x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w}, a_scale, P.ah[mi], P.al[mi], om);
           else split3(f32x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w}, P.ah[mi], P.am[mi], P.al[mi]);
         }
       }
@@ -611,7 +635,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
           const int r = wn * WTN + ni * 32 + lr, c = (2 * s2 + lh) ^ ((r >> 2) & 3);
           P.bh[ni] = __builtin_bit_cast(bf16x8_t, Bs[(0 * BN + r) * 4 + c]);
           if constexpr (NP == 3) P.bm[ni] = __builtin_bit_cast(bf16x8_t, Bs[(1 * BN + r) * 4 + c]);
-          P.bl[ni] = __builtin_bit_cast(bf16x8_t, Bs[((NP - 1) * BN + r) * 4 + c]);
+          if constexpr (NP >= 2) P.bl[ni] = __builtin_bit_cast(bf16x8_t, Bs[((NP - 1) * BN + r) * 4 + c]);
         } else {
           const int r = wn * WTN + ni * 32 + lr, sw = (r >> 1) & 7;
           const float4 lo = Bs[r * 8 + (c0 ^ sw)], hi = Bs[r * 8 + ((c0 + 1) ^ sw)];
@@ -620,6 +644,23 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
       }
     };
     auto mfma_phase = [&](const Pieces& P, bool with_dma) {
+      if constexpr (NP == 1) {
+        // fp16 x 1: the one product, straight into the main accumulator
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < TN; ++ni) {
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, P.ah[mi]),
+                                                                 __builtin_bit_cast(f16x8_t, P.bh[ni]), acc[mi][ni], 0, 0, 0);
+            if (with_dma) {
+              const int g = mi * TN + ni;     // 0 .. TM*TN-1
+#pragma unroll
+              for (int q = 0; q < ND; ++q)
+                if (q * (TM * TN) / ND == g) issue_one(q);
+            }
+          }
+        return;
+      }
       if constexpr (NP == 2) {
         // fp16 x 2: three products, the two small ones into the side accumulator
 #pragma unroll
@@ -756,6 +797,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
           mfma_phase(P0, false);
         }
         wait_vmcnt<(S - 2) * ND>();
+        // (the fragment reads of tile it have been ISSUED by now; they must also have RETURNED before any wave's DMA of
+        //  tile it+3 can land in this stage: found as a rare race in the one-piece instance, whose short MFMA phases let
+        //  the compiler sink the wait for these reads below the barrier)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();     // every wave is done reading tile it -- and, at the last tap, the planes
         issue_prepare(stage, it + S < nk);
         if constexpr (decltype(bnd)::value) {
@@ -794,6 +839,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
       load_split(stage, 1, P1, 0);      // VALU under ...
       mfma_phase(P0, false);            // ... the MFMAs of step 0
       wait_vmcnt<(S - 2) * ND>();       // tile it+1 landed (S = 3: tile it+2 may fly)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // ... and this wave's reads of tile it have returned (see the A-halo body)
       __builtin_amdgcn_s_barrier();     // every wave is done reading tile it
       issue_prepare(stage, it + S < nk);
       load_split(next, 0, P0, 0);       // first step of tile it+1 (zeros past the end) under ...
@@ -803,7 +849,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
     }
     }
     wait_vmcnt<0>();
-    if constexpr (NP == 2) ovf_report(om, p.ovf);
+    if constexpr (NP <= 2) ovf_report(om, p.ovf);
   } else {
 #pragma unroll
   for (int s = 0; s < S - 1; ++s) {
@@ -977,7 +1023,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] += acc2[i][j][r];
   }
-  if constexpr (NP == 2) {
+  if constexpr (NP <= 2) {
     // undo the operand scales (powers of two: exact)
     const float ia = 1.f / pow2_scale(p.a_amax), iw = 1.f / pow2_scale(p.w_amax);
 #pragma unroll
@@ -1473,7 +1519,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3p_kernel(const WgradArgs p, 
   constexpr int C4B = BN / 4, RPB = NT / C4B, BL = KT / RPB;
   constexpr int A_ROW = BM * 2, B_ROW = BN * 2;                  // bytes per plane row
   constexpr int A_PLANE = KT * A_ROW, B_PLANE = KT * B_ROW;
-  static_assert(NP == 2 || NP == 3, "planes");
+  static_assert(NP >= 1 && NP <= 3, "planes");
   constexpr int STAGE = NP * (A_PLANE + B_PLANE);
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
 
@@ -1559,8 +1605,14 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3p_kernel(const WgradArgs p, 
   for (int i = 0; i < BL; ++i) b_st[i] = NP * A_PLANE + plane_off(b_row + RPB * i, b_c4 >> 1, B_ROW) + 8 * (b_c4 & 1);
   float sg = 1.f, sx = 1.f;
   float om = 0.f;      // max |scaled operand| this thread split (ovf_report)
-  if constexpr (NP == 2) { sg = pow2_scale(p.g_amax); sx = pow2_scale(p.x_amax); }
+  if constexpr (NP <= 2) { sg = pow2_scale(p.g_amax); sx = pow2_scale(p.x_amax); }
   auto split_store = [&](const u32x4 v, unsigned char* dst, int plane_bytes, float sc) {
+    if constexpr (NP == 1) {
+      uint2 h2;
+      cvt4_f16(v, sc, h2, om);
+      *reinterpret_cast<uint2*>(dst) = h2;
+      return;
+    }
     if constexpr (NP == 2) {
       uint2 h2, l2;
       split2_f16(v, sc, h2, l2, om);
@@ -1629,7 +1681,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3p_kernel(const WgradArgs p, 
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
-  constexpr int NPR = NP == 3 ? 6 : 3;                 // products per group
+  constexpr int NPR = NP == 3 ? 6 : (NP == 2 ? 3 : 1);   // products per group
   constexpr int NI = AL + BL, NMF = 2 * NPR * TM * TN; // items and MFMAs per K-tile
   for (int it = 0; it < nk; ++it) {
     const unsigned char* cur = smem + (it & 1) * STAGE;
@@ -1647,13 +1699,13 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3p_kernel(const WgradArgs p, 
       for (int mi = 0; mi < TM; ++mi) {
         ah[mi] = frag(ab, a_rd[mi][0], a_rd[mi][1]);
         if constexpr (NP == 3) am[mi] = frag(ab + A_PLANE, a_rd[mi][0], a_rd[mi][1]);
-        al[mi] = frag(ab + (NP - 1) * A_PLANE, a_rd[mi][0], a_rd[mi][1]);
+        if constexpr (NP >= 2) al[mi] = frag(ab + (NP - 1) * A_PLANE, a_rd[mi][0], a_rd[mi][1]);
       }
 #pragma unroll
       for (int ni = 0; ni < TN; ++ni) {
         bh[ni] = frag(bb, b_rd[ni][0], b_rd[ni][1]);
         if constexpr (NP == 3) bm2[ni] = frag(bb + B_PLANE, b_rd[ni][0], b_rd[ni][1]);
-        bl[ni] = frag(bb + (NP - 1) * B_PLANE, b_rd[ni][0], b_rd[ni][1]);
+        if constexpr (NP >= 2) bl[ni] = frag(bb + (NP - 1) * B_PLANE, b_rd[ni][0], b_rd[ni][1]);
       }
 #pragma unroll
       for (int pc = 0; pc < NPR; ++pc)
@@ -1661,11 +1713,12 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3p_kernel(const WgradArgs p, 
         for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
           for (int ni = 0; ni < TN; ++ni) {
-            if constexpr (NP == 2) {
-              // al.bh, ah.bl into the side accumulator, ah.bh into the main one
-              const f16x8_t a = __builtin_bit_cast(f16x8_t, pc == 0 ? al[mi] : ah[mi]);
-              const f16x8_t b = __builtin_bit_cast(f16x8_t, pc == 1 ? bl[ni] : bh[ni]);
-              if (pc < 2) acc2[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc2[mi][ni], 0, 0, 0);
+            if constexpr (NP <= 2) {
+              // al.bh, ah.bl into the side accumulator, ah.bh into the main one (NP = 1: ah.bh only)
+              const int pq = NP == 1 ? 2 : pc;      // one plane: the main product only
+              const f16x8_t a = __builtin_bit_cast(f16x8_t, pq == 0 ? al[mi] : ah[mi]);
+              const f16x8_t b = __builtin_bit_cast(f16x8_t, pq == 1 ? bl[ni] : bh[ni]);
+              if (pq < 2) acc2[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc2[mi][ni], 0, 0, 0);
               else acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[mi][ni], 0, 0, 0);
             } else {
               const bf16x8_t a = pc == 0 ? al[mi] : (pc == 2 || pc == 3) ? am[mi] : ah[mi];
@@ -1678,8 +1731,10 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3p_kernel(const WgradArgs p, 
             for (int q_ = 0; q_ < NI; ++q_) {
               // (the last load slot is clamped: with 6 MFMAs and 3 items per K-tile -- NP = 2, BM = 64 -- it would fall
               // past the end, and the item's register would never be refilled)
+              // (both slots are clamped to the last MFMA: with few MFMAs per K-tile -- NP = 1, or NP = 2 at BM = 64 -- they
+              // would fall past the end, and the item would never be stored / its register never refilled)
               constexpr int LD_OFF = NMF / (2 * NI) + 1;
-              if (q_ * NMF / NI + 1 == g) store_item(q_, nxt);
+              if ((q_ * NMF / NI + 1 < NMF ? q_ * NMF / NI + 1 : NMF - 1) == g) store_item(q_, nxt);
               if ((q_ * NMF / NI + LD_OFF < NMF ? q_ * NMF / NI + LD_OFF : NMF - 1) == g) load_item(q_);
             }
           }
@@ -1693,8 +1748,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3p_kernel(const WgradArgs p, 
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] += acc2[i][j][r];
-  const float isc = NP == 2 ? (1.f / sg) * (1.f / sx) : 1.f;     // powers of two: exact
-  if constexpr (NP == 2) ovf_report(om, p.ovf);
+  const float isc = NP <= 2 ? (1.f / sg) * (1.f / sx) : 1.f;     // powers of two: exact
+  if constexpr (NP <= 2) ovf_report(om, p.ovf);
   // D[row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)][col = lane&31] of sub-tile (mi, ni)
   float* __restrict__ dst = p.slab + (long)ks * p.O * p.ND;
   const int lr = lane & 31, lh = lane >> 5;
@@ -1827,7 +1882,7 @@ __global__ __launch_bounds__(64 * (H7_WAVES + 1)) void wgrad7_halo_x3_kernel(con
   __shared__ __attribute__((aligned(16))) unsigned char Gp[2 * GBUF];
   float sg = 1.f, sx = 1.f;
   float om = 0.f;      // max |scaled operand| this thread split (ovf_report)
-  if constexpr (NP == 2) { sg = pow2_scale(p.g_amax); sx = pow2_scale(p.x_amax); }
+  if constexpr (NP <= 2) { sg = pow2_scale(p.g_amax); sx = pow2_scale(p.x_amax); }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ch = blockIdx.x % nch, r = blockIdx.x / nch;
@@ -1855,6 +1910,12 @@ __global__ __launch_bounds__(64 * (H7_WAVES + 1)) void wgrad7_halo_x3_kernel(con
     return __builtin_amdgcn_raw_buffer_load_b128(rgs, (int)voff, 0, 0);
   };
   auto split_store = [&](const u32x4 v, unsigned char* dst, int plane_bytes, float sc) {
+    if constexpr (NP == 1) {
+      uint2 h2;
+      cvt4_f16(v, sc, h2, om);
+      *reinterpret_cast<uint2*>(dst) = h2;
+      return;
+    }
     if constexpr (NP == 2) {
       uint2 h2, l2;
       split2_f16(v, sc, h2, l2, om);
@@ -1904,7 +1965,7 @@ __global__ __launch_bounds__(64 * (H7_WAVES + 1)) void wgrad7_halo_x3_kernel(con
       for (int j = 0; j < 4; ++j) ng[j] = load_g(lane + 64 * j, y + 2);
       __syncthreads();
     }
-    if constexpr (NP == 2) ovf_report(om, p.ovf);
+    if constexpr (NP <= 2) ovf_report(om, p.ovf);
     return;
   }
 
@@ -1934,6 +1995,10 @@ __global__ __launch_bounds__(64 * (H7_WAVES + 1)) void wgrad7_halo_x3_kernel(con
       for (int t = 0; t < 7; ++t) {
         const bf16x8_t xh = frag(Xrow, px + t), xm = NP == 3 ? frag(Xrow + W7X_XPLANE, px + t) : xh,
                        xl = frag(Xrow + (NP - 1) * W7X_XPLANE, px + t);
+        if constexpr (NP == 1) {
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, gh), __builtin_bit_cast(f16x8_t, xh), acc[t], 0, 0, 0);
+          continue;
+        }
         if constexpr (NP == 2) {
           acca[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, gl), __builtin_bit_cast(f16x8_t, xh), acca[t], 0, 0, 0);
           accb[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, gh), __builtin_bit_cast(f16x8_t, xl), accb[t], 0, 0, 0);
@@ -1952,8 +2017,8 @@ __global__ __launch_bounds__(64 * (H7_WAVES + 1)) void wgrad7_halo_x3_kernel(con
   }
   // D[o = 4 kq + e][i = c16] of tap (th, t)
   float* __restrict__ dst = p.slab + (long)((n * R + r) * nch + ch) * p.O * p.ND;
-  const float isc = NP == 2 ? (1.f / sg) * (1.f / sx) : 1.f;      // powers of two: exact
-  if constexpr (NP == 2) ovf_report(om, p.ovf);
+  const float isc = NP <= 2 ? (1.f / sg) * (1.f / sx) : 1.f;      // powers of two: exact
+  if constexpr (NP <= 2) ovf_report(om, p.ovf);
 #pragma unroll
   for (int t = 0; t < 7; ++t) {
     const int col = (th * 7 + t) * p.IP + cg * 16 + c16;
@@ -2082,7 +2147,7 @@ __global__ __launch_bounds__(64 * (H7_WAVES + 1)) void conv7_halo_x3_kernel(cons
   __shared__ __attribute__((aligned(16))) unsigned char Xp[8 * F7X_SLOT];
   float a_scale = 1.f, w_scale = 1.f;
   float om = 0.f;      // max |scaled operand| this thread split (ovf_report)
-  if constexpr (NP == 2) { a_scale = pow2_scale(p.a_amax); w_scale = pow2_scale(p.w_amax); }
+  if constexpr (NP <= 2) { a_scale = pow2_scale(p.a_amax); w_scale = pow2_scale(p.w_amax); }
   __shared__ __attribute__((aligned(16))) float Rs[2 * H7_WAVES * F7_CW * 16];   // [row parity][wave][pixel][16 co]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2103,6 +2168,12 @@ __global__ __launch_bounds__(64 * (H7_WAVES + 1)) void conv7_halo_x3_kernel(cons
     const int lpx = f >> 4, c4 = f & 15;
     if (lpx >= F7_CW + 6) return;
     unsigned char* dst = Xp + ((yy + 16) & 7) * F7X_SLOT + lpx * 128 + (((c4 >> 1) ^ (lpx & 7)) << 4) + 8 * (c4 & 1);
+    if constexpr (NP == 1) {
+      uint2 h2;
+      cvt4_f16(v, a_scale, h2, om);
+      *reinterpret_cast<uint2*>(dst) = h2;
+      return;
+    }
     if constexpr (NP == 2) {
       uint2 h2, l2;
       split2_f16(v, a_scale, h2, l2, om);
@@ -2171,7 +2242,7 @@ __global__ __launch_bounds__(64 * (H7_WAVES + 1)) void conv7_halo_x3_kernel(cons
       __syncthreads();                     // row y+4 visible, partial tiles of row y complete
     }
     sum_store(y1 - 1);
-    if constexpr (NP == 2) ovf_report(om, p.ovf);
+    if constexpr (NP <= 2) ovf_report(om, p.ovf);
     return;
   }
 
@@ -2189,10 +2260,11 @@ __global__ __launch_bounds__(64 * (H7_WAVES + 1)) void conv7_halo_x3_kernel(cons
     } else {
       f = f32x8{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     }
-    if constexpr (NP == 2) split2x8(f, w_scale, wh[s2], wl[s2], om);
+    if constexpr (NP == 1) cvt8_f16(f, w_scale, wh[s2], om);
+    else if constexpr (NP == 2) split2x8(f, w_scale, wh[s2], wl[s2], om);
     else split3(f, wh[s2], wm[s2], wl[s2]);
   }
-  const float isc = NP == 2 ? (1.f / a_scale) * (1.f / w_scale) : 1.f;      // powers of two: exact
+  const float isc = NP <= 2 ? (1.f / a_scale) * (1.f / w_scale) : 1.f;      // powers of two: exact
   __syncthreads();
 
   for (int y = y0; y < y1; ++y) {
@@ -2212,6 +2284,10 @@ __global__ __launch_bounds__(64 * (H7_WAVES + 1)) void conv7_halo_x3_kernel(cons
     };
     // small terms into two side accumulators, the main product into a third: three chains per pixel tile
     auto mfma6 = [&](int s2, int mt) {
+      if constexpr (NP == 1) {
+        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, fh[mt]), __builtin_bit_cast(f16x8_t, wh[s2]), acc[mt], 0, 0, 0);
+        return;
+      }
       if constexpr (NP == 2) {
         acca[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, fl[mt]), __builtin_bit_cast(f16x8_t, wh[s2]), acca[mt], 0, 0, 0);
         accb[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, fh[mt]), __builtin_bit_cast(f16x8_t, wl[s2]), accb[mt], 0, 0, 0);
@@ -2242,7 +2318,7 @@ __global__ __launch_bounds__(64 * (H7_WAVES + 1)) void conv7_halo_x3_kernel(cons
       for (int e = 0; e < 4; ++e) R[(16 * mt + 4 * kq + e) * 16 + c16] = (acc[mt][e] + (acca[mt][e] + accb[mt][e])) * isc;
     __syncthreads();
   }
-  if constexpr (NP == 2) ovf_report(om, p.ovf);      // the weights this wave split
+  if constexpr (NP <= 2) ovf_report(om, p.ovf);      // the weights this wave split
 }
 
 // 7x7, stride-1, pad-3 convolution from 12 physical channels to 64 (the generator's first layer, 11 -> 64,
@@ -2268,7 +2344,7 @@ __global__ __launch_bounds__(64 * (C12_WAVES + 1)) void conv7_c12_halo_x3_kernel
   __shared__ __attribute__((aligned(16))) unsigned char Xp[8 * C12_SLOTN];
   float a_scale = 1.f, w_scale = 1.f;
   float om = 0.f;      // max |scaled operand| this thread split (ovf_report)
-  if constexpr (NP == 2) { a_scale = pow2_scale(p.a_amax); w_scale = pow2_scale(p.w_amax); }
+  if constexpr (NP <= 2) { a_scale = pow2_scale(p.a_amax); w_scale = pow2_scale(p.w_amax); }
   __shared__ __attribute__((aligned(16))) float Rs[2 * C12_WAVES * 32 * 64];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2289,6 +2365,12 @@ __global__ __launch_bounds__(64 * (C12_WAVES + 1)) void conv7_c12_halo_x3_kernel
     if (f >= C12_XW * 3) return;
     const int lpx = f / 3, lc4 = f - lpx * 3;
     unsigned char* dst = Xp + ((yy + 16) & 7) * C12_SLOTN + lpx * 24 + lc4 * 8;
+    if constexpr (NP == 1) {
+      uint2 h2;
+      cvt4_f16(v, a_scale, h2, om);
+      *reinterpret_cast<uint2*>(dst) = h2;
+      return;
+    }
     if constexpr (NP == 2) {
       uint2 h2, l2;
       split2_f16(v, a_scale, h2, l2, om);
@@ -2374,14 +2456,14 @@ __global__ __launch_bounds__(64 * (C12_WAVES + 1)) void conv7_c12_halo_x3_kernel
         }
       }
     }
-    if constexpr (NP == 2) ovf_report(om, p.ovf);
+    if constexpr (NP <= 2) ovf_report(om, p.ovf);
     return;
   }
 
   // ================= MFMA waves: tap row th = wave.  Weights: k = tw * 12 + ci (84 real values, zeros up to 96);
   // B fragment of k16-step ks, n-tile ni: lane (co = 32 ni + (lane & 31), k = 16 ks + 8 (lane >> 5) .. +7)
   const int lr = lane & 31, lh = lane >> 5;
-  const float isc = NP == 2 ? (1.f / a_scale) * (1.f / w_scale) : 1.f;      // powers of two: exact
+  const float isc = NP <= 2 ? (1.f / a_scale) * (1.f / w_scale) : 1.f;      // powers of two: exact
   bf16x8_t wh[6][2], wm[6][2], wl[6][2];
 #pragma unroll
   for (int ks = 0; ks < 6; ++ks)
@@ -2392,7 +2474,8 @@ __global__ __launch_bounds__(64 * (C12_WAVES + 1)) void conv7_c12_halo_x3_kernel
       f32x8 f;
 #pragma unroll
       for (int j = 0; j < 8; ++j) f[j] = (co < p.Cout && k0 + j < 84) ? src[j] : 0.f;
-      if constexpr (NP == 2) split2x8(f, w_scale, wh[ks][ni], wl[ks][ni], om);
+      if constexpr (NP == 1) cvt8_f16(f, w_scale, wh[ks][ni], om);
+      else if constexpr (NP == 2) split2x8(f, w_scale, wh[ks][ni], wl[ks][ni], om);
       else split3(f, wh[ks][ni], wm[ks][ni], wl[ks][ni]);
     }
   __syncthreads();
@@ -2416,9 +2499,9 @@ __global__ __launch_bounds__(64 * (C12_WAVES + 1)) void conv7_c12_halo_x3_kernel
           const u32x4 v = {lo.x, lo.y, hi.x, hi.y};
           a[pl] = __builtin_bit_cast(bf16x8_t, v);
         }
-        if constexpr (NP == 2) {
+        if constexpr (NP <= 2) {
 #pragma unroll
-          for (int pc = 0; pc < 3; ++pc)
+          for (int pc = NP == 1 ? 2 : 0; pc < 3; ++pc)       // (one plane: the main product only)
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
               const f16x8_t av = __builtin_bit_cast(f16x8_t, pc == 0 ? a[1] : a[0]);
@@ -2449,7 +2532,7 @@ __global__ __launch_bounds__(64 * (C12_WAVES + 1)) void conv7_c12_halo_x3_kernel
     }
   }
   __syncthreads();
-  if constexpr (NP == 2) ovf_report(om, p.ovf);      // the weights this wave split
+  if constexpr (NP <= 2) ovf_report(om, p.ovf);      // the weights this wave split
 }
 
 // Weight gradient of a 3x3, stride-1, pad-1 convolution on 32-pixel-wide images (the residual blocks), FCD_PREC_BF16X3,
@@ -2509,8 +2592,14 @@ __global__ __launch_bounds__(64 * W3_WAVES) void wgrad3_halo_x3_kernel(const Wgr
   };
   float sg = 1.f, sx = 1.f;
   float om = 0.f;      // max |scaled operand| this thread split (ovf_report)
-  if constexpr (NP == 2) { sg = pow2_scale(p.g_amax); sx = pow2_scale(p.x_amax); }
+  if constexpr (NP <= 2) { sg = pow2_scale(p.g_amax); sx = pow2_scale(p.x_amax); }
   auto split_store = [&](const u32x4 v, unsigned char* dst, int plane_bytes, float sc) {
+    if constexpr (NP == 1) {
+      uint2 h2;
+      cvt4_f16(v, sc, h2, om);
+      *reinterpret_cast<uint2*>(dst) = h2;
+      return;
+    }
     if constexpr (NP == 2) {
       uint2 h2, l2;
       split2_f16(v, sc, h2, l2, om);
@@ -2610,9 +2699,9 @@ __global__ __launch_bounds__(64 * W3_WAVES) void wgrad3_halo_x3_kernel(const Wgr
           store_items(y + 3, y + 2, true);
           load_items(img, y + 4, y + 3);
         }
-        if constexpr (NP == 2) {
+        if constexpr (NP <= 2) {
 #pragma unroll
-          for (int pc = 0; pc < 3; ++pc)
+          for (int pc = NP == 1 ? 2 : 0; pc < 3; ++pc)       // (one plane: the main product only)
 #pragma unroll
             for (int ot = 0; ot < 2; ++ot) {
               const f16x8_t a = __builtin_bit_cast(f16x8_t, pc == 0 ? gl[ot] : gh[ot]);
@@ -2638,8 +2727,8 @@ __global__ __launch_bounds__(64 * W3_WAVES) void wgrad3_halo_x3_kernel(const Wgr
   }
   // D[o = 64 ob + 16 (2 oh + ot) + 4 kq + e][ci = 64 cb + 16 cq + c16] of tap t
   float* __restrict__ dst = p.slab + (long)split * p.O * p.ND;
-  const float isc = NP == 2 ? (1.f / sg) * (1.f / sx) : 1.f;      // powers of two: exact
-  if constexpr (NP == 2) ovf_report(om, p.ovf);
+  const float isc = NP <= 2 ? (1.f / sg) * (1.f / sx) : 1.f;      // powers of two: exact
+  if constexpr (NP <= 2) ovf_report(om, p.ovf);
 #pragma unroll
   for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
@@ -2673,7 +2762,7 @@ __global__ __launch_bounds__(64 * (C12_WAVES + 1)) void wgrad7_c12_halo_x3_kerne
   __shared__ __attribute__((aligned(16))) unsigned char Gp[2 * GBUF];
   float sg = 1.f, sx = 1.f;
   float om = 0.f;      // max |scaled operand| this thread split (ovf_report)
-  if constexpr (NP == 2) { sg = pow2_scale(p.g_amax); sx = pow2_scale(p.x_amax); }
+  if constexpr (NP <= 2) { sg = pow2_scale(p.g_amax); sx = pow2_scale(p.x_amax); }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ch = blockIdx.x % nch, r = blockIdx.x / nch;
@@ -2700,6 +2789,12 @@ __global__ __launch_bounds__(64 * (C12_WAVES + 1)) void wgrad7_c12_halo_x3_kerne
     return __builtin_amdgcn_raw_buffer_load_b128(rgs, (int)voff, 0, 0);
   };
   auto split_store = [&](const u32x4 v, unsigned char* dst, int plane_bytes, float sc) {
+    if constexpr (NP == 1) {
+      uint2 h2;
+      cvt4_f16(v, sc, h2, om);
+      *reinterpret_cast<uint2*>(dst) = h2;
+      return;
+    }
     if constexpr (NP == 2) {
       uint2 h2, l2;
       split2_f16(v, sc, h2, l2, om);
@@ -2746,7 +2841,7 @@ __global__ __launch_bounds__(64 * (C12_WAVES + 1)) void wgrad7_c12_halo_x3_kerne
       for (int j = 0; j < 8; ++j) ng[j] = load_g(lane + 64 * j, y + 2);
       __syncthreads();
     }
-    if constexpr (NP == 2) ovf_report(om, p.ovf);
+    if constexpr (NP <= 2) ovf_report(om, p.ovf);
     return;
   }
 
@@ -2785,9 +2880,9 @@ __global__ __launch_bounds__(64 * (C12_WAVES + 1)) void wgrad7_c12_halo_x3_kerne
         xl[t] = frag(Xrow + (NP - 1) * C12_ROWB, bt, bt + 4 * 24);
       }
       // piece pairs outermost (small terms first): consecutive MFMAs go to different accumulators
-      if constexpr (NP == 2) {
+      if constexpr (NP <= 2) {
 #pragma unroll
-        for (int pc = 0; pc < 3; ++pc)
+        for (int pc = NP == 1 ? 2 : 0; pc < 3; ++pc)         // (one plane: the main product only)
 #pragma unroll
           for (int t = 0; t < 3; ++t) {
             const f16x8_t a = __builtin_bit_cast(f16x8_t, pc == 0 ? gl : gh);
@@ -2812,8 +2907,8 @@ __global__ __launch_bounds__(64 * (C12_WAVES + 1)) void wgrad7_c12_halo_x3_kerne
   // D[o = 32 half + (e & 3) + 8 (e >> 2) + 4 (lane >> 5)][column j = 32 t + (lane & 31)] of tap row th; j = tw * 12 + ci < 84
   float* __restrict__ dst = p.slab + (long)((n * R + r) * nch + ch) * p.O * p.ND;
   const int lr = lane & 31, lh = lane >> 5;
-  const float isc = NP == 2 ? (1.f / sg) * (1.f / sx) : 1.f;      // powers of two: exact
-  if constexpr (NP == 2) ovf_report(om, p.ovf);
+  const float isc = NP <= 2 ? (1.f / sg) * (1.f / sx) : 1.f;      // powers of two: exact
+  if constexpr (NP <= 2) ovf_report(om, p.ovf);
 #pragma unroll
   for (int t = 0; t < 3; ++t) {
     const int j = 32 * t + lr;
@@ -3113,6 +3208,7 @@ void fill_gather_args(const FcdConvDesc* d, GatherArgs& a) {
   a.stats_cpp = 0;
   a.a_amax = a.w_amax = nullptr;
   a.ovf = nullptr;
+  a.onep = 0;
   a.out_amax = nullptr;
   a.out_amax_in_kernel = 0;
 }
@@ -3124,7 +3220,7 @@ extern "C" const char* fcd_last_conv_kernel(void) { return g_last_kernel; }
 extern "C" size_t fcd_conv_workspace_bytes(const FcdConvDesc* d) {
   if (!d || d->nphase < 1 || d->Cin <= 0 || d->KH <= 0 || d->KW <= 0) return 0;
   FcdConvDesc dd = *d;
-  if (dd.precision == FCD_PREC_F16X2) dd.precision = FCD_PREC_BF16X3;
+  if (dd.precision == FCD_PREC_F16X2 || dd.precision == FCD_PREC_F16) dd.precision = FCD_PREC_BF16X3;
   d = &dd;
   const int sk = resolve_splitk(d);
   if (sk <= 1) return 0;
@@ -3223,7 +3319,11 @@ int run_gather(const FcdConvDesc* d, GatherArgs& a, hipStream_t st) {
   a.out_amax_in_kernel = 0;
   if (const int rows = (a.bias || a.mask || a.res) ? 0 : halo12_rows(d, nullptr)) {
     const int nch = fcd_cdiv(d->GW, C12_CW), R = fcd_cdiv(d->GH, rows);
-    if (a.a_amax && a.w_amax) {
+    if (a.a_amax && a.w_amax && a.onep) {
+      note_kernel("conv7_c12_halo_x3_kernel<1>");
+      hipLaunchKernelGGL(conv7_c12_halo_x3_kernel<1>, dim3(nch * R, d->N), dim3(64 * (C12_WAVES + 1)), 0, st, a, rows, nch,
+                         (size_t)a.N * a.IH * a.IW * a.Cin * 4);
+    } else if (a.a_amax && a.w_amax) {
       note_kernel("conv7_c12_halo_x3_kernel<2>");
       hipLaunchKernelGGL(conv7_c12_halo_x3_kernel<2>, dim3(nch * R, d->N), dim3(64 * (C12_WAVES + 1)), 0, st, a, rows, nch,
                          (size_t)a.N * a.IH * a.IW * a.Cin * 4);
@@ -3237,7 +3337,11 @@ int run_gather(const FcdConvDesc* d, GatherArgs& a, hipStream_t st) {
   if (const int rows = halo7_fwd_rows(d, a)) {
     const int nch = fcd_cdiv(d->GW, F7_CW), R = fcd_cdiv(d->GH, rows);
     if (d->precision == FCD_PREC_BF16X3 && d->CoutP % 4 == 0 && !getenv("FCD_NO_HALO7X")) {
-      if (a.a_amax && a.w_amax) {
+      if (a.a_amax && a.w_amax && a.onep) {
+        note_kernel("conv7_halo_x3_kernel<1>");
+        hipLaunchKernelGGL(conv7_halo_x3_kernel<1>, dim3(nch * R, d->N), dim3(64 * (H7_WAVES + 1)), 0, st, a, rows, nch,
+                           (size_t)a.N * a.IH * a.IW * a.Cin * 4);
+      } else if (a.a_amax && a.w_amax) {
         note_kernel("conv7_halo_x3_kernel<2>");
         hipLaunchKernelGGL(conv7_halo_x3_kernel<2>, dim3(nch * R, d->N), dim3(64 * (H7_WAVES + 1)), 0, st, a, rows, nch,
                            (size_t)a.N * a.IH * a.IW * a.Cin * 4);
@@ -3265,7 +3369,11 @@ int run_gather(const FcdConvDesc* d, GatherArgs& a, hipStream_t st) {
     constexpr int X3 = FCD_PREC_BF16X3;
 #define FCD_LAUNCH_PRESPLIT(BM_, BN_, WM_, WN_, S_, AH_)                                                                       \
   do {                                                                                                                        \
-    if (h2) {                                                                                                                 \
+    if (h2 && a.onep) {                                                                                                       \
+      note_kernel("conv_gather_dma_kernel<%d, %d, %d, %d, %d, 2, false, true, %s, 1>", BM_, BN_, WM_, WN_, S_, AH_ ? "true" : "false"); \
+      hipLaunchKernelGGL((conv_gather_dma_kernel<BM_, BN_, WM_, WN_, S_, X3, false, true, AH_, 1>), grid, dim3(512), 0, st, a, \
+                         in_bytes, w_bytes);                                                                                  \
+    } else if (h2) {                                                                                                          \
       note_kernel("conv_gather_dma_kernel<%d, %d, %d, %d, %d, 2, false, true, %s, 2>", BM_, BN_, WM_, WN_, S_, AH_ ? "true" : "false"); \
       hipLaunchKernelGGL((conv_gather_dma_kernel<BM_, BN_, WM_, WN_, S_, X3, false, true, AH_, 2>), grid, dim3(512), 0, st, a, \
                          in_bytes, w_bytes);                                                                                  \
@@ -3348,12 +3456,14 @@ struct NormDesc {
   FcdConvDesc d;
   bool h2;       // two fp16 weight planes (format 2): both maxima required
   bool h2opt;    // fp32 weights split inside the kernel (the 7x7 halo kernels, format 3): two-piece form if both maxima are given
+  bool onep;     // FCD_PREC_F16: the same kernels and operands, high pieces only (one MFMA per product group)
 };
 NormDesc normalise(const FcdConvDesc* d) {
   NormDesc n;
   n.d = *d;
   n.h2 = n.h2opt = false;
-  if (d->precision == FCD_PREC_F16X2) {
+  n.onep = d->precision == FCD_PREC_F16;
+  if (d->precision == FCD_PREC_F16X2 || d->precision == FCD_PREC_F16) {
     n.d.precision = FCD_PREC_BF16X3;
     if (validate_conv(&n.d) == FCD_OK) {
       if (wants_split_weights(&n.d)) {
@@ -3402,6 +3512,7 @@ extern "C" int fcd_conv_gather(const FcdConvDesc* d, const float* in, const floa
   a.in = in; a.w = w_packed; a.bias = bias; a.mask = mask_src; a.res = residual; a.out = out;
   a.slab = (float*)workspace;
   a.a_amax = a_amax; a.w_amax = w_amax;
+  a.onep = nd.onep ? 1 : 0;
   a.ovf = a_amax ? fcd_overflow_flag_current() : nullptr;
   a.out_amax = reinterpret_cast<unsigned*>(d->out_amax);
   rc = run_gather(d, a, fcd_stream(stream));
@@ -3463,6 +3574,7 @@ int conv_stats_impl(const FcdConvDesc* d, const float* in, const float* w_packed
   a.in = in; a.w = w_packed; a.bias = nullptr; a.mask = nullptr; a.res = nullptr; a.out = out;
   a.slab = (float*)workspace;
   a.a_amax = a_amax; a.w_amax = w_amax;
+  a.onep = nd.onep ? 1 : 0;
   a.ovf = a_amax ? fcd_overflow_flag_current() : nullptr;
   const int chunks = fused_stats_chunks(d);
   const long hw = (long)d->OH * d->OW;
@@ -3550,7 +3662,9 @@ static int halo12w_plan(const FcdWgradDesc* d, int* rows, int* R, int* nch, int*
 // The halo form of the 3x3 weight gradient on 32-pixel-wide images under FCD_PREC_BF16X3 (wgrad3_halo_x3_kernel):
 // number of slabs (= splits over whole images), or 0; *ipS = images per split.
 static int halo3w_plan(const FcdWgradDesc* d, int* ipS) {
-  if (d->splitk > 0 || (d->precision != FCD_PREC_BF16X3 && d->precision != FCD_PREC_F16X2) || getenv("FCD_NO_WGRAD3")) return 0;
+  if (d->splitk > 0 || (d->precision != FCD_PREC_BF16X3 && d->precision != FCD_PREC_F16X2 && d->precision != FCD_PREC_F16) ||
+      getenv("FCD_NO_WGRAD3"))
+    return 0;
   if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->GW != 32 || d->BW != 32 || d->BH != d->GH) return 0;
   if (d->IP % 64 != 0 || d->OP % 64 != 0 || d->O <= 32 || d->GH < 2) return 0;
   const long blocks = (long)(d->OP / 64) * (d->IP / 64);
@@ -3595,8 +3709,8 @@ static int validate_wgrad(const FcdWgradDesc* d) {
 
 extern "C" size_t fcd_wgrad_workspace_bytes(const FcdWgradDesc* d) {
   if (!d || d->O <= 0 || d->IP <= 0 || d->KH <= 0 || d->KW <= 0) return 0;
-  FcdWgradDesc dd = *d;                  // FCD_PREC_F16X2 exists only in the 3x3 halo kernel; elsewhere it is BF16X3
-  if (dd.precision == FCD_PREC_F16X2) dd.precision = FCD_PREC_BF16X3;
+  FcdWgradDesc dd = *d;                  // FCD_PREC_F16X2 / _F16: kernels are chosen by shape as under BF16X3
+  if (dd.precision == FCD_PREC_F16X2 || dd.precision == FCD_PREC_F16) dd.precision = FCD_PREC_BF16X3;
   d = &dd;
   int rows, R, nch;
   int halo = halo7_plan(d, &rows, &R, &nch);
@@ -3612,8 +3726,11 @@ extern "C" int fcd_conv_wgrad(const FcdWgradDesc* d, const float* gsmall, const 
   FcdWgradDesc dd = *d;
   // FCD_PREC_F16X2: the two-plane forms need both maxima; without them (and for the shapes that have no such form)
   // the weight gradient runs as FCD_PREC_BF16X3 -- unlike the convolutions there is no operand format tied to the choice
-  const bool want_h2 = d->precision == FCD_PREC_F16X2 && d->g_amax && d->x_amax;
-  if (d->precision == FCD_PREC_F16X2) dd.precision = FCD_PREC_BF16X3;
+  // (FCD_PREC_F16: the same kernels with the high pieces only, NP = 1)
+  const bool f16fam = d->precision == FCD_PREC_F16X2 || d->precision == FCD_PREC_F16;
+  const bool want_h2 = f16fam && d->g_amax && d->x_amax;
+  const bool onep = d->precision == FCD_PREC_F16;
+  if (f16fam) dd.precision = FCD_PREC_BF16X3;
   const float* g_amax = want_h2 ? d->g_amax : nullptr;
   const float* x_amax = want_h2 ? d->x_amax : nullptr;
   d = &dd;
@@ -3652,7 +3769,12 @@ extern "C" int fcd_conv_wgrad(const FcdWgradDesc* d, const float* gsmall, const 
     a.splitk = halo;
     dim3 grid(h_nch * h_R, d->N * (d->IP / 16));
     if (d->precision == FCD_PREC_BF16X3 && !getenv("FCD_NO_WGRAD7X")) {
-      if (want_h2) {
+      if (want_h2 && onep) {
+        a.g_amax = g_amax; a.x_amax = x_amax;
+        note_kernel("wgrad7_halo_x3_kernel<1>");
+        hipLaunchKernelGGL(wgrad7_halo_x3_kernel<1>, grid, dim3(64 * (H7_WAVES + 1)), 0, st, a, h_rows, h_R, h_nch,
+                           (size_t)a.P * a.OP * 4, (size_t)a.N * a.BH * a.BW * a.IP * 4);
+      } else if (want_h2) {
         a.g_amax = g_amax; a.x_amax = x_amax;
         note_kernel("wgrad7_halo_x3_kernel<2>");
         hipLaunchKernelGGL(wgrad7_halo_x3_kernel<2>, grid, dim3(64 * (H7_WAVES + 1)), 0, st, a, h_rows, h_R, h_nch,
@@ -3672,7 +3794,12 @@ extern "C" int fcd_conv_wgrad(const FcdWgradDesc* d, const float* gsmall, const 
     a.splitk = slabs3;
     const int ncb = d->IP / 64;
     dim3 grid((d->OP / 64) * ncb, slabs3);
-    if (want_h2) {
+    if (want_h2 && onep) {
+      a.g_amax = g_amax; a.x_amax = x_amax;
+      note_kernel("wgrad3_halo_x3_kernel<1>");
+      hipLaunchKernelGGL(wgrad3_halo_x3_kernel<1>, grid, dim3(64 * W3_WAVES), 0, st, a, ipS, ncb,
+                         (size_t)a.P * a.OP * 4, (size_t)a.N * a.BH * a.BW * a.IP * 4);
+    } else if (want_h2) {
       a.g_amax = g_amax; a.x_amax = x_amax;
       note_kernel("wgrad3_halo_x3_kernel<2>");
       hipLaunchKernelGGL(wgrad3_halo_x3_kernel<2>, grid, dim3(64 * W3_WAVES), 0, st, a, ipS, ncb,
@@ -3686,7 +3813,12 @@ extern "C" int fcd_conv_wgrad(const FcdWgradDesc* d, const float* gsmall, const 
   } else if (int hv = 0, slabs12 = halo12w_plan(d, &h_rows, &h_R, &h_nch, &hv); slabs12) {
     a.splitk = slabs12;
     dim3 grid(h_nch * h_R, d->N * hv);
-    if (want_h2) {
+    if (want_h2 && onep) {
+      a.g_amax = g_amax; a.x_amax = x_amax;
+      note_kernel("wgrad7_c12_halo_x3_kernel<1>");
+      hipLaunchKernelGGL(wgrad7_c12_halo_x3_kernel<1>, grid, dim3(64 * (C12_WAVES + 1)), 0, st, a, h_rows, h_R, h_nch, hv,
+                         (size_t)a.P * a.OP * 4, (size_t)a.N * a.BH * a.BW * a.IP * 4);
+    } else if (want_h2) {
       a.g_amax = g_amax; a.x_amax = x_amax;
       note_kernel("wgrad7_c12_halo_x3_kernel<2>");
       hipLaunchKernelGGL(wgrad7_c12_halo_x3_kernel<2>, grid, dim3(64 * (C12_WAVES + 1)), 0, st, a, h_rows, h_R, h_nch, hv,
@@ -3714,7 +3846,13 @@ extern "C" int fcd_conv_wgrad(const FcdWgradDesc* d, const float* gsmall, const 
     a.tiles_m = fcd_cdiv(d->O, bm); a.tiles_n = fcd_cdiv(a.ND, 128);
     dim3 grid(a.tiles_m * a.tiles_n, a.splitk);
     const size_t gsb = (size_t)a.P * a.OP * 4, xbb = (size_t)a.N * a.BH * a.BW * a.IP * 4;
-    if (want_h2) {
+    if (want_h2 && onep) {
+      a.g_amax = g_amax; a.x_amax = x_amax;
+      note_kernel("conv_wgrad_x3p_kernel<%d, %d, %d, 1>", bm, bm == 64 ? 2 : 4, bm == 64 ? 4 : 2);
+      if (bm == 64) hipLaunchKernelGGL((conv_wgrad_x3p_kernel<64, 2, 4, 1>), grid, dim3(512), 0, st, a, gsb, xbb);
+      else if (bm == 128) hipLaunchKernelGGL((conv_wgrad_x3p_kernel<128, 4, 2, 1>), grid, dim3(512), 0, st, a, gsb, xbb);
+      else hipLaunchKernelGGL((conv_wgrad_x3p_kernel<256, 4, 2, 1>), grid, dim3(512), 0, st, a, gsb, xbb);
+    } else if (want_h2) {
       a.g_amax = g_amax; a.x_amax = x_amax;
       note_kernel("conv_wgrad_x3p_kernel<%d, %d, %d, 2>", bm, bm == 64 ? 2 : 4, bm == 64 ? 4 : 2);
       if (bm == 64) hipLaunchKernelGGL((conv_wgrad_x3p_kernel<64, 2, 4, 2>), grid, dim3(512), 0, st, a, gsb, xbb);

@@ -358,7 +358,7 @@ class _GeneratorFn(torch.autograd.Function):
         acts = [ops.g_prologue(x, c, cp)]      # acts[i] = input of layer i
         # PREC_F16X2: max |acts[i]| as device scalars (written by the norm kernel that produces the activation, or by
         # an absmax launch where a conv that wants it has another producer); amx_ok[i]: already filled
-        h2 = prec == L.PREC_F16X2
+        h2 = prec in L.F16_FAMILY
         amx = torch.zeros((len(plan) + 1, ops.AMAX_SLOTS), dtype=torch.float32, device=x.device) if h2 else None
         amx_ok = [False] * (len(plan) + 1)
         if h2:
@@ -477,7 +477,7 @@ class _GeneratorFn(torch.autograd.Function):
             pidx.append(k)
             k += 1 if ly.norm is None else 3
         pending_res = {}       # activation index -> residual gradient to add
-        h2 = prec == L.PREC_F16X2 or prec_w == L.PREC_F16X2
+        h2 = prec in L.F16_FAMILY or prec_w in L.F16_FAMILY
         amx, amx_ok = ctx.amx, ctx.amx_ok
         if h2 and amx is None:
             amx, amx_ok = torch.zeros((len(plan) + 1, ops.AMAX_SLOTS), dtype=torch.float32, device=x.device), [False] * (len(plan) + 1)
@@ -537,7 +537,7 @@ class _GeneratorFn(torch.autograd.Function):
                     dz_ok = True
                 return gmx[li]
             # weight gradient (PREC_F16X2: the kernels with a two-plane form want max |.| of both operands)
-            h2_w = h2 and prec_w == L.PREC_F16X2
+            h2_w = h2 and prec_w in L.F16_FAMILY
             if needs[p0]:
                 sink = grad_sink(ly.conv.weight, True)     # arena-backed: accumulate into p.grad in place
                 if ly.kind == "conv":

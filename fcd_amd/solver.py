@@ -220,11 +220,19 @@ class FCDSolver(nn.Module):
         its 3x3 layers) split each operand, scaled by a power of two taken from the tensor's max |.|, into two fp16
         pieces: three MFMAs per product group instead of six, same parity bars.  The maxima come from the kernels
         that write the operands (InstanceNorm apply / backward).  The discriminator runs as under fp32x3.
-        'bf16': operands rounded to bf16, fp32 accumulate."""
+        'fp16': the reduced-precision variant ("16-bit MFMA" of BASELINE.json configs[1]): fp32x2's kernels, operands and
+        maxima in the generator, but only the high fp16 piece of every operand (11 significant bits; bf16 has 8) and ONE
+        MFMA per product group; the discriminator with operands rounded to bf16.  fp32 accumulate, fp32 tensors in HBM.
+        'bf16': operands rounded to bf16 at the MFMA fragment everywhere, fp32 accumulate."""
         p, pw = {"fp32": (L.PREC_F32, None), "fp32x3": (L.PREC_BF16X3, None), "bf16": (L.PREC_BF16, None),
-                 "fp32x2": (L.PREC_F16X2, None)}[precision]
+                 "fp32x2": (L.PREC_F16X2, None), "fp16": (L.PREC_F16, None)}[precision]
         for net in (self.G, self.D):
-            net.precision = L.PREC_BF16X3 if (p == L.PREC_F16X2 and net is self.D) else p
+            if net is self.D and p in L.F16_FAMILY:
+                # the discriminator has no producer of the maxima (no InstanceNorm): split bf16 pieces under fp32x2,
+                # plain bf16 operands under the reduced-precision variant
+                net.precision = L.PREC_BF16X3 if p == L.PREC_F16X2 else L.PREC_BF16
+            else:
+                net.precision = p
             net.wgrad_precision = pw
             for m in net.modules():          # drop packed weights of the other precision's layout
                 if hasattr(m, "_packed"):
@@ -516,7 +524,7 @@ class FCDSolver(nn.Module):
             self._shared_fake = None
         self._flush_pending()          # no G update this step: nothing used D in between
         self.global_step += 1
-        if self.precision == "fp32x2" and (self.global_step == 1 or self.global_step % self.overflow_check_every == 0):
+        if self.precision in ("fp32x2", "fp16") and (self.global_step == 1 or self.global_step % self.overflow_check_every == 0):
             # fp32x2's overflow guard (include/fcd_hip.h: fcd_set_overflow_flag): polled after the first step, where a
             # mis-wired maximum shows, and then every `overflow_check_every` steps (a poll is a host-device sync)
             ops.check_overflow(self.device)
@@ -568,7 +576,7 @@ class FCDSolver(nn.Module):
 
     def check_overflow(self) -> None:
         """fp32x2 only: raise if any kernel since the last poll saw a scaled operand beyond 2^15 (stale max |.|)."""
-        if self.precision == "fp32x2" and self.device.type == "cuda":
+        if self.precision in ("fp32x2", "fp16") and self.device.type == "cuda":
             ops.check_overflow(self.device)
 
     def sync_running_stats(self) -> None:

@@ -50,6 +50,11 @@ extern "C" {
                              a power of two and split into two fp16 pieces, three fp16 MFMAs (22+ operand bits; fp32
                              accumulate); every other shape runs as FCD_PREC_BF16X3.  Needs FcdConvDesc.a_amax / w_amax. */
 
+#define FCD_PREC_F16 4    /* the reduced-precision variant ("16-bit MFMA", BASELINE.json configs[1]): FCD_PREC_F16X2's kernels, operand
+                             formats (weight format 2 / 3, the same maxima, the same overflow guard) and fall-backs, but only the
+                             high fp16 piece of every operand is used: ONE fp16 MFMA per product group, 11 significant bits per
+                             operand (bf16 has 8), fp32 accumulate.  Per-kernel rel-err <= 1e-3 (north_star's bf16 bar: 1e-2). */
+
 /* activation codes accepted where an InstanceNorm entry point takes `act_slope` (values outside [0,1]) */
 #define FCD_ACT_SILU 2.0f
 #define FCD_ACT_MISH 3.0f

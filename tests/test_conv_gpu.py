@@ -547,6 +547,12 @@ def test_wgrad3_halo_x3(dev, shape, monkeypatch):
         assert relerr(acc.cpu() - 0.25, ref) <= 1e-5
 
 
+# The scaled-fp16 family: (precision code, bar against float64, template suffix of the kernel that must have run).
+# FCD_PREC_F16X2 (two pieces, three MFMAs: fp32-faithful, 1e-6) and FCD_PREC_F16 (the reduced-precision variant: the
+# same kernels and operands with the high piece only, one MFMA; north_star's bar for the 16-bit path is 1e-2, the
+# 11-bit pieces hold 1e-3)
+F16_FAM = [pytest.param((3, 1e-6, b"2>"), id="fp32x2"), pytest.param((4, 1e-3, b"1>"), id="fp16")]
+
 # FCD_PREC_F16X2: (O, I, N, H, W, form, scale of the activation operand)
 H2_GEOMS = [
     (256, 256, 32, 32, 32, "fwd", 1.0),
@@ -556,8 +562,9 @@ H2_GEOMS = [
 ]
 
 
+@pytest.mark.parametrize("fam", F16_FAM)
 @pytest.mark.parametrize("geom", H2_GEOMS)
-def test_gather_a_halo_f16x2(dev, geom):
+def test_gather_a_halo_f16x2(dev, fam, geom):
     """FCD_PREC_F16X2 on the A-halo 3x3 convolutions: operands scaled by a power of two taken from their max |.|
     (ops.absmax: FCD_AMAX_SLOTS per-block maxima) and split into two fp16 pieces, three fp16 MFMAs per product group.
     Against torch in float64 the error stays at the BF16X3 level (<= 1e-6 of max |result|, the bar of the exact-fp32
@@ -577,7 +584,7 @@ def test_gather_a_halo_f16x2(dev, geom):
             if outliers:
                 x.view(-1)[::40961] *= 1000.0
             b = torch.randn(O, generator=gen) * sc
-            d = g.fwd_desc(N, H, W, precision=L.PREC_F16X2, act_slope=0.01)
+            d = g.fwd_desc(N, H, W, precision=fam[0], act_slope=0.01)
             assert ops.weight_format(d) == 2
             xd = to_nhwc(x, g.IP).to(dev)
             ops.set_amax(d, ops.absmax(xd), wa)
@@ -590,7 +597,7 @@ def test_gather_a_halo_f16x2(dev, geom):
             if outliers:
                 gy.view(-1)[::40961] *= 1000.0
             mask = torch.randn(N, I, H, W, generator=gen)
-            d = g.adj_desc(N, H, W, precision=L.PREC_F16X2, mask_slope=0.01)
+            d = g.adj_desc(N, H, W, precision=fam[0], mask_slope=0.01)
             assert ops.weight_format(d) == 2
             gd, md = to_nhwc(gy, g.OP).to(dev), to_nhwc(mask, g.IP).to(dev)
             ops.set_amax(d, ops.absmax(gd), wa)
@@ -598,8 +605,8 @@ def test_gather_a_halo_f16x2(dev, geom):
             got = ops.conv_gather(d, gd, wp, mask=md)
             ref = F.conv_transpose2d(gy.double(), wt.double(), None, 1, 1) * torch.where(mask > 0, 1.0, 0.01)
             cref = I
-        assert L.load().fcd_last_conv_kernel().endswith(b"true, true, 2>")
-        assert relerr(from_nhwc(got.cpu(), cref).double(), ref) <= 1e-6
+        assert L.load().fcd_last_conv_kernel().endswith(b"true, true, " + fam[2])
+        assert relerr(from_nhwc(got.cpu(), cref).double(), ref) <= fam[1]
 
 
 def test_f16x2_without_amax_is_refused(dev):
@@ -616,8 +623,9 @@ def test_f16x2_without_amax_is_refused(dev):
         ops.set_amax(d, torch.zeros(1, device=dev), torch.zeros(1, device=dev))
 
 
+@pytest.mark.parametrize("fam", F16_FAM)
 @pytest.mark.parametrize("shape", [(256, 256, 16, 4, 1.0, 1.0), (128, 192, 40, 5, 2e-5, 30.0), (254, 128, 30, 3, 500.0, 1e-3)])
-def test_wgrad3_halo_f16x2(dev, shape):
+def test_wgrad3_halo_f16x2(dev, fam, shape):
     """FCD_PREC_F16X2 weight gradient of the residual blocks' 3x3 convolutions (wgrad3_halo_x3_kernel<2>): both operands
     as two fp16 planes of the scaled values; <= 1e-6 of max |dW| from torch in float64 across operand magnitudes, and
     accumulation into an existing gradient."""
@@ -628,26 +636,27 @@ def test_wgrad3_halo_f16x2(dev, shape):
     x = torch.randn(n, I, h, 32, generator=gen) * sx
     gy = torch.randn(n, O, h, 32, generator=gen) * sg
     xd, gd = to_nhwc(x, g.IP).to(dev), to_nhwc(gy, g.OP).to(dev)
-    d = ops.set_wgrad_amax(g.wgrad_desc(n, h, 32, precision=L.PREC_F16X2), ops.absmax(gd), ops.absmax(xd))
+    d = ops.set_wgrad_amax(g.wgrad_desc(n, h, 32, precision=fam[0]), ops.absmax(gd), ops.absmax(xd))
     dw = ops.conv_wgrad(d, gd, xd)
-    assert L.load().fcd_last_conv_kernel() == b"wgrad3_halo_x3_kernel<2>"
+    assert L.load().fcd_last_conv_kernel() == b"wgrad3_halo_x3_kernel<" + fam[2]
     ref = torch.nn.grad.conv2d_weight(x.double(), (O, I, 3, 3), gy.double(), stride=1, padding=1)
-    assert relerr(dw.cpu(), ref) <= 1e-6
+    assert relerr(dw.cpu(), ref) <= fam[1]
     base = float(ref.abs().max()) * 0.25
     acc = torch.full_like(dw, base)
-    d2 = ops.set_wgrad_amax(g.wgrad_desc(n, h, 32, precision=L.PREC_F16X2, accumulate=True), ops.absmax(gd), ops.absmax(xd))
+    d2 = ops.set_wgrad_amax(g.wgrad_desc(n, h, 32, precision=fam[0], accumulate=True), ops.absmax(gd), ops.absmax(xd))
     ops.conv_wgrad(d2, gd, xd, dw=acc)
-    assert relerr(acc.cpu() - base, ref) <= 1e-5
+    assert relerr(acc.cpu() - base, ref) <= 10 * fam[1]
     # without the maxima the same descriptor runs the BF16X3 form
-    dw3 = ops.conv_wgrad(g.wgrad_desc(n, h, 32, precision=L.PREC_F16X2), gd, xd)
+    dw3 = ops.conv_wgrad(g.wgrad_desc(n, h, 32, precision=fam[0]), gd, xd)
     assert L.load().fcd_last_conv_kernel() == b"wgrad3_halo_x3_kernel"
     assert relerr(dw3.cpu(), ref) <= 1e-6
 
 
+@pytest.mark.parametrize("fam", F16_FAM)
 @pytest.mark.parametrize("shape", [(128, 64, 6, 32, 32, 1.0, 3e-4), (256, 128, 5, 16, 16, 40.0, 1.0),
                                    (128, 256, 3, 16, 16, 1e-3, 1.0), (96, 64, 2, 24, 40, 1.0, 1.0), (48, 24, 2, 16, 16, 1.0, 1.0),
                                    (64, 64, 7, 8, 8, 5.0, 0.1)])
-def test_wgrad_x3p_f16x2(dev, shape):
+def test_wgrad_x3p_f16x2(dev, fam, shape):
     """FCD_PREC_F16X2 weight gradient of the 4x4 stride-2 layers (conv_wgrad_x3p_kernel<.., 2>: operands split once per
     workgroup into two fp16 planes of the scaled values): <= 1e-6 of max |dW| from torch in float64 across operand
     magnitudes, ragged channel counts and accumulation."""
@@ -658,16 +667,16 @@ def test_wgrad_x3p_f16x2(dev, shape):
     big = torch.randn(n, I, 2 * h, 2 * w, generator=gen) * sx
     small = torch.randn(n, O, h, w, generator=gen) * sg
     bd, sd = to_nhwc(big, g.IP).to(dev), to_nhwc(small, g.OP).to(dev)
-    d = ops.set_wgrad_amax(g.wgrad_desc(n, 2 * h, 2 * w, precision=L.PREC_F16X2), ops.absmax(sd), ops.absmax(bd))
+    d = ops.set_wgrad_amax(g.wgrad_desc(n, 2 * h, 2 * w, precision=fam[0]), ops.absmax(sd), ops.absmax(bd))
     dw = ops.conv_wgrad(d, sd, bd)
-    assert L.load().fcd_last_conv_kernel().startswith(b"conv_wgrad_x3p_kernel") and L.load().fcd_last_conv_kernel().endswith(b", 2>")
+    assert L.load().fcd_last_conv_kernel().startswith(b"conv_wgrad_x3p_kernel") and L.load().fcd_last_conv_kernel().endswith(b", " + fam[2])
     ref = torch.nn.grad.conv2d_weight(big.double(), (O, I, 4, 4), small.double(), stride=2, padding=1)
-    assert relerr(dw.cpu(), ref) <= 1e-6
+    assert relerr(dw.cpu(), ref) <= fam[1]
     base = float(ref.abs().max()) * 0.5
     acc = torch.full_like(dw, base)
-    d2 = ops.set_wgrad_amax(g.wgrad_desc(n, 2 * h, 2 * w, precision=L.PREC_F16X2, accumulate=True), ops.absmax(sd), ops.absmax(bd))
+    d2 = ops.set_wgrad_amax(g.wgrad_desc(n, 2 * h, 2 * w, precision=fam[0], accumulate=True), ops.absmax(sd), ops.absmax(bd))
     ops.conv_wgrad(d2, sd, bd, dw=acc)
-    assert relerr(acc.cpu() - base, ref) <= 1e-5
+    assert relerr(acc.cpu() - base, ref) <= 10 * fam[1]
 
 
 def test_absmax_and_norm_amax(dev):
@@ -705,8 +714,9 @@ H2_S2_GEOMS = [
 ]
 
 
+@pytest.mark.parametrize("fam", F16_FAM)
 @pytest.mark.parametrize("geom", H2_S2_GEOMS)
-def test_gather_per_tap_f16x2(dev, geom):
+def test_gather_per_tap_f16x2(dev, fam, geom):
     """FCD_PREC_F16X2 in the per-tap gather form (every shape that takes pre-split weights under BF16X3): activation
     fragments scaled and split into two fp16 pieces in registers, weights as two fp16 planes ([phase][plane] for the
     four-phase adjoint of a stride-2 layer); <= 1e-6 of max |result| from torch in float64, with the epilogue operands
@@ -721,33 +731,34 @@ def test_gather_per_tap_f16x2(dev, geom):
     if form == "fwd":
         x = torch.randn(N, I, 2 * H, 2 * W, generator=gen) * sc
         xd = to_nhwc(x, g.IP).to(dev)
-        d = g.fwd_desc(N, 2 * H, 2 * W, precision=L.PREC_F16X2)
+        d = g.fwd_desc(N, 2 * H, 2 * W, precision=fam[0])
         assert ops.weight_format(d) == 2
         ops.set_amax(d, ops.absmax(xd), wa)
         wp = ops.pack_weight_fwd_h2(wd, g, wa)
         z, mean, rstd, varu = ops.conv_gather_stats(d, xd, wp, want_var=True)
         ref = F.conv2d(x.double(), wt.double(), None, 2, 1)
-        assert relerr(from_nhwc(z.cpu(), O).double(), ref) <= 1e-6
-        assert relerr(mean.cpu().double(), ref.mean(dim=(2, 3))) <= 1e-5
-        assert relerr(varu.cpu().double(), ref.var(dim=(2, 3), unbiased=True)) <= 1e-5
+        assert relerr(from_nhwc(z.cpu(), O).double(), ref) <= fam[1]
+        assert relerr(mean.cpu().double(), ref.mean(dim=(2, 3))) <= 10 * fam[1]
+        assert relerr(varu.cpu().double(), ref.var(dim=(2, 3), unbiased=True)) <= 10 * fam[1]
     else:
         gy = torch.randn(N, O, H, W, generator=gen) * sc
         mask = torch.randn(N, I, 2 * H, 2 * W, generator=gen)
         res = torch.randn(N, I, 2 * H, 2 * W, generator=gen) * sc
         gd, md, rd = to_nhwc(gy, g.OP).to(dev), to_nhwc(mask, g.IP).to(dev), to_nhwc(res, g.IP).to(dev)
-        d = g.adj_desc(N, H, W, precision=L.PREC_F16X2, mask_slope=0.2)
+        d = g.adj_desc(N, H, W, precision=fam[0], mask_slope=0.2)
         assert ops.weight_format(d) == 2
         ops.set_amax(d, ops.absmax(gd), wa)
         wp = ops.pack_weight_adj_h2(wd, g, wa)
         got = ops.conv_gather(d, gd, wp, mask=md, residual=rd)
         ref = F.conv_transpose2d(gy.double(), wt.double(), None, 2, 1) * torch.where(mask > 0, 1.0, 0.2) + res
-        assert relerr(from_nhwc(got.cpu(), I).double(), ref) <= 1e-6
-    assert L.load().fcd_last_conv_kernel().endswith(b"false, 2>")
+        assert relerr(from_nhwc(got.cpu(), I).double(), ref) <= fam[1]
+    assert L.load().fcd_last_conv_kernel().endswith(b"false, " + fam[2])
 
 
+@pytest.mark.parametrize("fam", F16_FAM)
 @pytest.mark.parametrize("case", [(64, 11, 2, 40, 72, "fwd", 30.0), (10, 64, 2, 33, 64, "adj", 1e-4), (10, 64, 3, 24, 70, "fwd", 1.0),
                                   (16, 64, 1, 16, 32, "fwd", 1.0)])
-def test_conv7_halo_f16x2(dev, case):
+def test_conv7_halo_f16x2(dev, fam, case):
     """The 7x7 image-layer kernels under FCD_PREC_F16X2 (weight format 3: fp32 packs, operands scaled and split into
     two fp16 pieces inside the kernel when both maxima are attached): <= 1e-6 of max |result| from torch in float64; the
     same descriptor without maxima runs the BF16X3 form."""
@@ -761,7 +772,7 @@ def test_conv7_halo_f16x2(dev, case):
     xd = to_nhwc(x, g.IP if form == "fwd" else g.OP).to(dev)
     wd = wt.to(dev)
     def mk():
-        d_ = g.fwd_desc(n, h, w, precision=L.PREC_F16X2) if form == "fwd" else g.adj_desc(n, h, w, precision=L.PREC_F16X2)
+        d_ = g.fwd_desc(n, h, w, precision=fam[0]) if form == "fwd" else g.adj_desc(n, h, w, precision=fam[0])
         d_.splitk = 1          # (small test shapes would otherwise take split-K and the generic kernel)
         return d_
     d = mk()
@@ -769,16 +780,17 @@ def test_conv7_halo_f16x2(dev, case):
     wp = ops.pack_weight_fwd(wd, g) if form == "fwd" else ops.pack_weight_adj(wd, g)
     ops.set_amax(d, ops.absmax(xd), ops.absmax(wd))
     got = ops.conv_gather(d, xd, wp)
-    assert L.load().fcd_last_conv_kernel().endswith(b"halo_x3_kernel<2>")
+    assert L.load().fcd_last_conv_kernel().endswith(b"halo_x3_kernel<" + fam[2])
     ref = F.conv2d(x.double(), wt.double(), None, 1, 3) if form == "fwd" else F.conv_transpose2d(x.double(), wt.double(), None, 1, 3)
-    assert relerr(from_nhwc(got.cpu(), cout).double(), ref) <= 1e-6
+    assert relerr(from_nhwc(got.cpu(), cout).double(), ref) <= fam[1]
     plain = ops.conv_gather(mk(), xd, wp)
     assert L.load().fcd_last_conv_kernel().endswith(b"halo_x3_kernel")
     assert relerr(from_nhwc(plain.cpu(), cout).double(), ref) <= 1e-6
 
 
+@pytest.mark.parametrize("fam", F16_FAM)
 @pytest.mark.parametrize("case", [(10, 64, 2, 40, 72, 1e-3, 1.0), (64, 11, 3, 33, 70, 1.0, 25.0), (16, 16, 1, 70, 64, 1.0, 1.0)])
-def test_wgrad7_halo_f16x2(dev, case):
+def test_wgrad7_halo_f16x2(dev, fam, case):
     """Weight gradients of the 7x7 image layers under FCD_PREC_F16X2 with both maxima attached (two fp16 planes of the
     scaled gradient and input rows): <= 1e-6 of max |dW| from torch in float64."""
     from fcd_amd import _lib as L, ops
@@ -788,11 +800,11 @@ def test_wgrad7_halo_f16x2(dev, case):
     x = torch.randn(n, I, h, w, generator=gen) * sx
     gy = torch.randn(n, O, h, w, generator=gen) * sg
     xd, gd = to_nhwc(x, g.IP).to(dev), to_nhwc(gy, g.OP).to(dev)
-    d = ops.set_wgrad_amax(g.wgrad_desc(n, h, w, precision=L.PREC_F16X2), ops.absmax(gd), ops.absmax(xd))
+    d = ops.set_wgrad_amax(g.wgrad_desc(n, h, w, precision=fam[0]), ops.absmax(gd), ops.absmax(xd))
     dw = ops.conv_wgrad(d, gd, xd)
-    assert L.load().fcd_last_conv_kernel().endswith(b"halo_x3_kernel<2>")
+    assert L.load().fcd_last_conv_kernel().endswith(b"halo_x3_kernel<" + fam[2])
     ref = torch.nn.grad.conv2d_weight(x.double(), (O, I, 7, 7), gy.double(), stride=1, padding=3)
-    assert relerr(dw.cpu(), ref) <= 1e-6
+    assert relerr(dw.cpu(), ref) <= fam[1]
 
 
 @pytest.mark.parametrize("case", [(256, 256, 3, 1, 1, 8, 32, 32, 2, 0), (128, 64, 4, 2, 1, 4, 64, 64, 2, 0), (10, 64, 7, 1, 3, 2, 64, 64, 2, 0),
