@@ -550,7 +550,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
     float a_scale = 1.f, om = 0.f;         // om: max |scaled activation| this thread split (ovf_report)
     if constexpr (NP <= 2) a_scale = pow2_scale(p.a_amax);
     // ---- AH: halo geometry, the staged next slice, the planes
-    const int W2 = p.GW + 2, APX = (BM / p.GW + 2) * W2, PB = APX * 64;      // halo row pitch, halo pixels, plane bytes
+    // (KH x KW taps at stride 1 on a GW-wide grid, 3 x 3 with pad 1 or the 2 x 2 taps of one phase of a 4 x 4 stride-2
+    //  adjoint with pad 0 / 1: the halo region has KH - 1 extra rows and KW - 1 extra columns)
+    const int W2 = p.GW + p.KW - 1, APX = (BM / p.GW + p.KH - 1) * W2, PB = APX * 64;   // halo row pitch, halo pixels, plane bytes
     const int ah_y0 = (tm * BM - n0 * ghw) / p.GW;                          // first output row of this tile in its image
     int hbase[TM];                                                          // halo pixel of this lane's rows at tap (0, 0)
     constexpr int NLH = (AH_MAXPX * 8 + NT - 1) / NT;                       // float4 of a slice per thread (7)
@@ -569,7 +571,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
 #pragma unroll
       for (int j = 0; j < NLH; ++j) {
         const int f = tid + NT * j, hp = f >> 3, c4 = f & 7;
-        const int hy = hp / W2, hx = hp - hy * W2, iy = ah_y0 - 1 + hy, ix = hx - 1;
+        const int hy = hp / W2, hx = hp - hy * W2, iy = ah_y0 - pad_h + hy, ix = hx - pad_w;
         const unsigned okm = 0u - (unsigned)((int)(hp < APX) & (int)(cs * 32 < p.Cin) & (int)(iy >= 0) & (int)(iy < p.IH) &
                                              (int)(ix >= 0) & (int)(ix < p.IW));
         const unsigned voff = ((unsigned)(((iy * p.IW + ix) * p.Cin + cs * 32 + c4 * 4) * 4) & okm) | (OOB & ~okm);
@@ -786,8 +788,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
     load_split(0, 0, P0, 0);
     int stage = 0;
     if constexpr (AH) {
-      // nk = 9 taps x Cin / 32 slices; taps 0 .. 7 of a slice run the plain body (one basic block), the last tap
-      // carries the slice change between its two k16-steps
+      // nk = T taps x Cin / 32 slices (T = 9, or 4 for a phase of a stride-2 adjoint); all taps of a slice but the last run
+      // the plain body (one basic block), the last tap carries the slice change between its two k16-steps
       auto body = [&](auto bnd, int it, int toff, int toff_next, int cs) {
         const int next = stage == S - 1 ? 0 : stage + 1;
         if constexpr (NP == 2) {
@@ -822,9 +824,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
       int it = 0;
       for (int cs = 0; cs * 32 < p.Cin; ++cs) {
         int toff = 0, twc = 0;
-        for (int t9 = 0; t9 < 8; ++t9) {
-          const bool wrap = twc == 2;
-          const int toff_next = toff + (wrap ? W2 - 2 : 1);
+        for (int t9 = 0; t9 < T - 1; ++t9) {
+          const bool wrap = twc == p.KW - 1;
+          const int toff_next = toff + (wrap ? W2 - (p.KW - 1) : 1);
           body(std::false_type{}, it, toff, toff_next, cs);
           toff = toff_next;
           twc = wrap ? 0 : twc + 1;
@@ -3269,10 +3271,20 @@ bool gather_ahalo(const FcdConvDesc* d, int rows) {
   if (!wants_split_weights(d) || resolve_splitk(d) != 1) return false;
   int bm, bn;
   gather_tile(d, bm, bn);
-  if (bn != 128 || d->KH != 3 || d->KW != 3 || d->nphase != 1 || d->istride != 1 || d->ostride != 1) return false;
-  if (d->pad_h[0] != 1 || d->pad_w[0] != 1 || d->ooff_h[0] || d->ooff_w[0]) return false;
-  if (d->GH != d->IH || d->GW != d->IW || d->OH != d->GH || d->OW != d->GW) return false;
+  if (d->istride != 1 || d->GH != d->IH || d->GW != d->IW) return false;
   if (d->GW != 32 && d->GW != 64) return false;
+  if (d->KH == 3 && d->KW == 3 && d->nphase == 1 && d->ostride == 1) {
+    if (bn != 128 || d->pad_h[0] != 1 || d->pad_w[0] != 1 || d->ooff_h[0] || d->ooff_w[0]) return false;
+    if (d->OH != d->GH || d->OW != d->GW) return false;
+  } else if (d->KH == 2 && d->KW == 2 && d->ostride == 2 && d->nphase == 4 && !getenv("FCD_NO_HALO2")) {
+    // the four 2 x 2-tap phases of a 4 x 4 stride-2 adjoint (ConvTranspose2d, the data gradient of the strided
+    // convolutions): each phase is a stride-1 gather on the input grid with pad 0 or 1
+    for (int ph = 0; ph < 4; ++ph)
+      if (d->pad_h[ph] < 0 || d->pad_h[ph] > 1 || d->pad_w[ph] < 0 || d->pad_w[ph] > 1) return false;
+    if (bn != 128 && bn != 64) return false;
+  } else {
+    return false;
+  }
   return d->GH % (rows / d->GW) == 0;
 }
 
@@ -3386,13 +3398,16 @@ int run_gather(const FcdConvDesc* d, GatherArgs& a, hipStream_t st) {
     if (gather_big_tile(d)) {
       a.tiles_m = fcd_cdiv(a.M, 256);
       grid = dim3(a.tiles_m * a.tiles_n, a.nphase * a.splitk);
-      if (gather_ahalo(d, 256)) FCD_LAUNCH_PRESPLIT(256, 128, 4, 2, 3, true);
+      if (bn == 128 && gather_ahalo(d, 256)) FCD_LAUNCH_PRESPLIT(256, 128, 4, 2, 3, true);
       else if (bn == 128) FCD_LAUNCH_PRESPLIT(256, 128, 4, 2, 2, false);
+      else if (gather_ahalo(d, 256)) FCD_LAUNCH_PRESPLIT(256, 64, 8, 1, 3, true);
       else FCD_LAUNCH_PRESPLIT(256, 64, 8, 1, 3, false);
     } else if (bn == 128 && gather_ahalo(d, 128)) {
       FCD_LAUNCH_PRESPLIT(128, 128, 4, 2, 3, true);
     } else if (bn == 128) {
       FCD_LAUNCH_PRESPLIT(128, 128, 4, 2, 3, false);
+    } else if (gather_ahalo(d, 128)) {
+      FCD_LAUNCH_PRESPLIT(128, 64, 4, 2, 3, true);
     } else {
       FCD_LAUNCH_PRESPLIT(128, 64, 4, 2, 3, false);
     }

@@ -710,7 +710,10 @@ H2_S2_GEOMS = [
     (128, 64, 8, 32, 32, "fwd", 1.0),        # 128-row tiles, 64 input channels
     (256, 128, 32, 16, 16, "fwd", 2e-4),     # 256 x 128 tiles
     (256, 128, 9, 16, 16, "adj", 50.0),      # four phases, 128 output channels
-    (128, 64, 33, 32, 32, "adj", 1.0),       # 256 x 64 tiles (8 x 1 waves), ragged last tile
+    (128, 64, 33, 32, 32, "adj", 1.0),       # 256 x 64 tiles (8 x 1 waves): A-halo form of the four 2 x 2-tap phases
+    (256, 128, 32, 32, 32, "adj", 1.0),      # 256 x 128 tiles, A-halo form, 32-wide grid (the 256 -> 128 up-sampling layer)
+    (128, 64, 9, 64, 64, "adj", 3e-3),       # 64-wide grid, 128 x 64 A-halo tiles
+    (128, 64, 16, 64, 64, "adj", 1.0),       # 64-wide grid, 256 x 64 A-halo tiles (the 128 -> 64 up-sampling layer)
 ]
 
 
@@ -752,7 +755,10 @@ def test_gather_per_tap_f16x2(dev, fam, geom):
         got = ops.conv_gather(d, gd, wp, mask=md, residual=rd)
         ref = F.conv_transpose2d(gy.double(), wt.double(), None, 2, 1) * torch.where(mask > 0, 1.0, 0.2) + res
         assert relerr(from_nhwc(got.cpu(), I).double(), ref) <= fam[1]
-    assert L.load().fcd_last_conv_kernel().endswith(b"false, " + fam[2])
+    kern = L.load().fcd_last_conv_kernel()
+    assert kern.endswith(b", " + fam[2])
+    if form == "adj" and H in (32, 64):
+        assert kern.endswith(b"true, true, " + fam[2]), kern        # the A-halo form took the launch
 
 
 @pytest.mark.parametrize("fam", F16_FAM)

@@ -283,10 +283,10 @@ class _FakeSync:
         self.async_calls += 1
         return [("handle", flat)]
 
-    def finish(self, handle):
+    def finish(self, handle, tag=""):
         self.finished += len(handle)
 
-    def allreduce_flat(self, flat):
+    def allreduce_flat(self, flat, tag=""):
         self.sync_calls += 1
 
     def allreduce(self, params):
