@@ -52,6 +52,24 @@ def _worker(rank, world, port, out):
     sync.allreduce_flat(ar.grad)
     ok = ok and all(torch.allclose(p_.grad, e, atol=1e-6) for p_, e in zip(ps, exp)) and ar.intact()
     ok = ok and float(ar.grad.abs().sum()) > 0 and ar.flat.numel() % 64 == 0
+    # diagnostics of the gradient exchange (bench.py prints them for N > 1): every finish() is timed per tag, the
+    # version of a parameter written by broadcast_params moves (packed operands keyed on it are rebuilt), and the
+    # reducer describes its spans
+    v0 = lin.weight._version
+    sync.broadcast_params([lin])
+    ok = ok and lin.weight._version > v0
+    sync.timing = []
+    for p_ in ps:
+        p_.grad.fill_(float(rank))
+    sync.allreduce_flat(ar.grad, "D")
+    sync.finish(sync.allreduce_flat_async(ar.grad), "G")
+    ex = sync.exposed_ms()
+    ok = ok and set(ex) == {"D", "G"} and all(v["calls"] == 1 and v["stream_wait_ms"] >= 0 and v["bytes"] == ar.grad.numel() * 4
+                                              for v in ex.values()) and sync.timing == []
+    ok = ok and all(bool((p_.grad == (world - 1) / 2).all()) for p_ in ps)       # (the arena's padding stays 0)
+    desc = sync.bucketed(ar, 0.05).describe()
+    ok = ok and abs(sum(desc["spans_mb"]) * (1 << 20) - ar.grad.numel() * 4) < 0.02 * (1 << 20) * len(desc["spans_mb"]) + 1 \
+        and sum(desc["params_per_span"]) == len(ps)
     out[rank] = ok and not all(torch.equal(a, p.grad) for a, p in zip(local, params))
     dist.destroy_process_group()
 
