@@ -57,6 +57,7 @@ __device__ __forceinline__ float epilogue_value(float v, int co, long o, const G
 __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const GatherArgs p) {
   const long total = (long)p.nphase * p.M * p.CoutP;
   const int ghw = p.GH * p.GW;
+  float omax = 0.f;
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
     const int co = (int)(idx % p.CoutP);
     const long pm = idx / p.CoutP;
@@ -68,7 +69,28 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const GatherArg
     const int a = rem / p.GW, b = rem - a * p.GW;
     const long o = (((long)n * p.OH + a * p.ostride + p.ooff_h[phase]) * p.OW + b * p.ostride +
                     p.ooff_w[phase]) * p.CoutP + co;
-    p.out[o] = co < p.Cout ? epilogue_value(v, co, o, p) : 0.f;
+    const float r = co < p.Cout ? epilogue_value(v, co, o, p) : 0.f;
+    p.out[o] = r;
+    omax = fmaxf(omax, fabsf(r));
+  }
+  if (p.out_amax) {
+    // max |out| of this block into its slot (FcdConvDesc.out_amax; same protocol as the gather kernels' epilogue and
+    // norm.hip's block_absmax: one plain read-max-write per block while the grid has at most FCD_AMAX_SLOTS blocks)
+    __shared__ float wave_max[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) omax = fmaxf(omax, __shfl_xor(omax, o));
+    if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = omax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const float m = fmaxf(fmaxf(wave_max[0], wave_max[1]), fmaxf(wave_max[2], wave_max[3]));
+      const unsigned b = __float_as_uint(m);
+      unsigned* slot = p.out_amax + (blockIdx.x & (FCD_AMAX_SLOTS - 1));
+      if (gridDim.x <= FCD_AMAX_SLOTS) {
+        if (b > *slot) *slot = b;
+      } else if (b > __builtin_nontemporal_load(slot)) {
+        atomicMax(slot, b);
+      }
+    }
   }
 }
 
@@ -3417,6 +3439,7 @@ int run_gather(const FcdConvDesc* d, GatherArgs& a, hipStream_t st) {
     if (a.splitk > 1) {
       const long total = (long)a.nphase * a.M * a.CoutP;
       const int blocks = (int)std::min<long>(fcd_cdiv(total, 256), 4096);
+      if (want_amax) { a.out_amax = want_amax; a.out_amax_in_kernel = 1; }      // the reduction writes the final values
       hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, a);
       rc = fcd_check_launch("conv_splitk_reduce");
     }
@@ -3443,6 +3466,7 @@ int run_gather(const FcdConvDesc* d, GatherArgs& a, hipStream_t st) {
   if (a.splitk > 1) {
     const long total = (long)a.nphase * a.M * a.CoutP;
     const int blocks = (int)std::min<long>(fcd_cdiv(total, 256), 4096);
+    if (want_amax && !(bm == 128 && bn == 16 && d->precision != FCD_PREC_BF16)) { a.out_amax = want_amax; a.out_amax_in_kernel = 1; }
     hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, a);
     rc = fcd_check_launch("conv_splitk_reduce");
   }

@@ -25,7 +25,7 @@ import torch.nn as nn
 from . import _lib as L
 from . import ops
 from .arena import grad_sink
-from .generator import ConvParams, _act_slope
+from .generator import ConvParams, WeightMaxima, _act_slope
 from .ops import ConvGeom
 
 class _State:
@@ -58,6 +58,12 @@ def input_grad_only(*modules):
 
 def _input_only(mod) -> bool:
     return bool(getattr(mod, "input_only", False) or _state.input_only)
+
+
+class _Acts(list):
+    """The per-layer activations of one forward call; under the scaled-fp16 precisions also their maxima
+    (``amx[i]`` = max |acts[i]| as AMAX_SLOTS partial maxima, written by the convolution that produced the tensor)."""
+    amx = None
 
 
 class _ConvAct(nn.Sequential):
@@ -118,6 +124,7 @@ class Discriminator(nn.Module):
         self._g2 = ConvGeom(c_dim, cin, ks, 1, 0)
         self._grad_hook = None        # parallel.BucketedReducer while a data-parallel D step runs
         self.input_only = False       # input_grad_only(self): backward skips parameter gradients
+        self._wmax = WeightMaxima(self._convs)     # max |weight| of the six layers in one launch per optimizer step
 
     def _flat_params(self):
         out = []
@@ -142,11 +149,24 @@ class _DiscriminatorFn(torch.autograd.Function):
         if ch != mod.num_channels:
             raise RuntimeError(f"Discriminator: expected {mod.num_channels} bands")
         prec = mod.precision
-        acts = [ops.nchw_to_nhwc(x, mod._geoms[0].IP)]
+        acts = _Acts([ops.nchw_to_nhwc(x, mod._geoms[0].IP)])
+        # Scaled-fp16 precisions (fp32x2: FCD_PREC_F16X2, fp16: FCD_PREC_F16): D has no InstanceNorm to record the maxima,
+        # so every convolution leaves max |output| for the next one (FcdConvDesc.out_amax: from its epilogue, or from the
+        # split-K reduction of the deep layers); only the input image needs a pass of its own
+        h2 = prec in L.F16_FAMILY
+        if h2:
+            mod._wmax.refresh()
+            acts.amx = torch.zeros((len(mod._convs) + 1, ops.AMAX_SLOTS), dtype=torch.float32, device=x.device)
+            ops.absmax(acts[0], out=acts.amx[0])
         for li, (cv, g) in enumerate(zip(mod._convs, mod._geoms)):
             a = acts[-1]
             d = g.fwd_desc(n, a.shape[1], a.shape[2], precision=prec, act_slope=mod._slopes[li])
-            acts.append(ops.conv_gather(d, a, cv.operand("fwd", g, d), bias=params[2 * li + 1]))
+            wp = cv.operand("fwd", g, d)
+            if h2:
+                if d.w_amax:
+                    d.a_amax = acts.amx[li].data_ptr()
+                ops.set_out_amax(d, acts.amx[li + 1])
+            acts.append(ops.conv_gather(d, a, wp, bias=params[2 * li + 1]))
         top = acts[-1]
         if top.shape[1] < mod._g2.k or top.shape[2] < mod._g2.k:
             raise RuntimeError("Discriminator: input smaller than image_size")
@@ -219,6 +239,12 @@ class _DBackwardFn(torch.autograd.Function):
             hook.param_ready(mod.conv1.weight)
         gzs = [None] * nl          # gzs[l] = masked gradient at layer l's pre-activation
         gx = None
+        # scaled-fp16 precisions: gamx[l] = max |gzs[l]| (the heads' gradient by a pass of its own, the others from the
+        # epilogue of the adjoint convolution that writes them)
+        h2 = prec in L.F16_FAMILY and getattr(acts, "amx", None) is not None
+        gamx = torch.zeros((nl, ops.AMAX_SLOTS), dtype=torch.float32, device=dev) if h2 else None
+        if h2 and gz is not None:
+            ops.absmax(gz, out=gamx[nl - 1])
         for li in range(mod._n_feat - 1 if only_feat else nl - 1, -1, -1):
             if g_feat is not None and li == mod._n_feat - 1:
                 # gradient arriving at the exposed feature map: mask it and add
@@ -226,6 +252,9 @@ class _DBackwardFn(torch.autograd.Function):
                 L.check(L.load().fcd_lrelu_bwd(L.ptr(gf), L.ptr(acts[li + 1]), L.ptr(gf), gf.numel(), slopes[li],
                                                L.stream()), "lrelu_bwd")
                 gz = gf if gz is None else gz + gf
+                if h2:
+                    gamx[li].zero_()
+                    ops.absmax(gz, out=gamx[li])
             gzs[li] = gz
             g = mod._geoms[li]
             a_in = acts[li]
@@ -233,6 +262,8 @@ class _DBackwardFn(torch.autograd.Function):
                 cv = mod._convs[li]
                 sink = grad_sink(cv.weight, True)
                 wd = g.wgrad_desc(n, a_in.shape[1], a_in.shape[2], precision=prec_w, accumulate=sink is not None)
+                if h2 and prec_w in L.F16_FAMILY:
+                    ops.set_wgrad_amax(wd, gamx[li], acts.amx[li])
                 dw = ops.conv_wgrad(wd, gz, a_in, dw=sink)
                 grads[2 * li] = None if sink is not None else dw
                 bsink = grad_sink(cv.bias, gz.shape[3] == g.O)
@@ -245,12 +276,21 @@ class _DBackwardFn(torch.autograd.Function):
             if li == 0:
                 if want_x:
                     d = g.adj_desc(n, gz.shape[1], gz.shape[2], precision=prec)
-                    g0 = ops.conv_gather(d, gz, mod._convs[0].operand("adj", g, d))
+                    wp = mod._convs[0].operand("adj", g, d)
+                    if h2 and d.w_amax:
+                        d.a_amax = gamx[0].data_ptr()
+                    g0 = ops.conv_gather(d, gz, wp)
                     gx = ops.nhwc_to_nchw(g0, mod.num_channels)
                 break
             d = g.adj_desc(n, gz.shape[1], gz.shape[2], precision=prec, mask_slope=slopes[li - 1])
-            gz = ops.conv_gather(d, gz, mod._convs[li].operand("adj", g, d), mask=a_in)
+            wp = mod._convs[li].operand("adj", g, d)
+            if h2:
+                if d.w_amax:
+                    d.a_amax = gamx[li].data_ptr()
+                ops.set_out_amax(d, gamx[li - 1])
+            gz = ops.conv_gather(d, gz, wp, mask=a_in)
         ctx.mod, ctx.acts, ctx.prec, ctx.gzs = mod, acts, prec, gzs
+        ctx.gamx = gamx
         ctx.g_src, ctx.g_cls = g_src, g_cls
         ctx.set_materialize_grads(False)
         if gx is None:
@@ -276,6 +316,12 @@ class _DBackwardFn(torch.autograd.Function):
         hook = mod._grad_hook
         final = hook is not None and any(needs) and hook.pass_begin()
         u = ops.nchw_to_nhwc(gg_x.contiguous(), mod._geoms[0].IP)
+        gamx = ctx.gamx
+        h2 = prec in L.F16_FAMILY and gamx is not None
+        uamx = None
+        if h2:
+            uamx = torch.zeros((nl + 1, ops.AMAX_SLOTS), dtype=torch.float32, device=u.device)
+            ops.absmax(u, out=uamx[0])
         for li in range(nl):
             g = mod._geoms[li]
             if needs[2 * li]:
@@ -283,6 +329,8 @@ class _DBackwardFn(torch.autograd.Function):
                     raise NotImplementedError("double backward through a feature-only backward of D")
                 sink = grad_sink(mod._convs[li].weight, True)
                 wd = g.wgrad_desc(n, u.shape[1], u.shape[2], precision=prec_w, accumulate=sink is not None)
+                if h2 and prec_w in L.F16_FAMILY:
+                    ops.set_wgrad_amax(wd, gamx[li], uamx[li])
                 dw = ops.conv_wgrad(wd, gzs[li], u, dw=sink)
                 out[2 * li] = None if sink is not None else dw
             if needs[2 * li + 1] and grad_sink(mod._convs[li].bias, True) is None:
@@ -291,7 +339,12 @@ class _DBackwardFn(torch.autograd.Function):
                 hook.param_ready(mod._convs[li].weight)
                 hook.param_ready(mod._convs[li].bias)
             d = g.fwd_desc(n, u.shape[1], u.shape[2], precision=prec, mask_slope=mod._slopes[li])
-            u = ops.conv_gather(d, u, mod._convs[li].operand("fwd", g, d), mask=acts[li + 1])
+            wp = mod._convs[li].operand("fwd", g, d)
+            if h2:
+                if d.w_amax:
+                    d.a_amax = uamx[li].data_ptr()
+                ops.set_out_amax(d, uamx[li + 1])
+            u = ops.conv_gather(d, u, wp, mask=acts[li + 1])
         if needs[2 * nl] and ctx.g_src is not None:
             sink = grad_sink(mod.conv1.weight, True)
             dw = ops.head_wgrad(ctx.g_src, u, mod._g1.I, 3, 1, dw=sink, accumulate=sink is not None)
@@ -305,7 +358,7 @@ class _DBackwardFn(torch.autograd.Function):
             hook.param_ready(mod.conv1.weight)
             hook.param_ready(mod.conv2.weight)
         # d/d g_src, d/d g_cls (linear) are not needed by the GP: grad_outputs is a constant
-        ctx.gzs = None
+        ctx.gzs = ctx.gamx = None
         return (None,) * 8 + tuple(out)
 
 

@@ -12,6 +12,7 @@ and the (optional) RCCL process group.
 from __future__ import annotations
 
 import gc
+import os
 from argparse import Namespace
 from typing import Dict, Iterable, Optional
 
@@ -195,6 +196,10 @@ class FCDSolver(nn.Module):
         self._val_cm = None
         self.freeze_host_objects = True             # gc.freeze() after the first train_step (see there)
         self.overflow_check_every = 64              # fp32x2: poll the overflow word every so many train steps
+        # fp32x2 / fp16: the discriminator on the scaled-fp16 kernels too (maxima handed from layer to layer through
+        # FcdConvDesc.out_amax).  Parity-tested, but measured level with BF16X3 / bf16 in both modes (DESIGN.md section 6d:
+        # its weight-bound layers gain nothing), so it is off by default; FCD_D_H2=1 for A/B runs
+        self.d_scaled_fp16 = os.environ.get("FCD_D_H2", "0") == "1"
         self._host_frozen = False
         self.build_model()
         self.D.register_forward_pre_hook(self._flush_pending)
@@ -227,9 +232,9 @@ class FCDSolver(nn.Module):
         p, pw = {"fp32": (L.PREC_F32, None), "fp32x3": (L.PREC_BF16X3, None), "bf16": (L.PREC_BF16, None),
                  "fp32x2": (L.PREC_F16X2, None), "fp16": (L.PREC_F16, None)}[precision]
         for net in (self.G, self.D):
-            if net is self.D and p in L.F16_FAMILY:
-                # the discriminator has no producer of the maxima (no InstanceNorm): split bf16 pieces under fp32x2,
-                # plain bf16 operands under the reduced-precision variant
+            if net is self.D and p in L.F16_FAMILY and (self.D.smooth or not self.d_scaled_fp16):
+                # SiLU / Mish discriminators keep their un-fused activation launches and no maxima bookkeeping: split bf16
+                # pieces under fp32x2, plain bf16 operands under the reduced-precision variant
                 net.precision = L.PREC_BF16X3 if p == L.PREC_F16X2 else L.PREC_BF16
             else:
                 net.precision = p

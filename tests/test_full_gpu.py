@@ -133,6 +133,35 @@ def test_full_g_step(full, prec):
     print("full G-step", prec, ": worst error / bar =", check_grads(s.G, "g", sc, prec))
 
 
+def test_full_steps_with_scaled_fp16_discriminator(full):
+    """FCDSolver.d_scaled_fp16 (off by default: measured level with BF16X3): the discriminator on the two-piece fp16
+    kernels under fp32x2, its activations' and gradients' maxima handed from convolution to convolution through
+    FcdConvDesc.out_amax (epilogue or split-K reduction), through forward, backward and the gradient penalty's double
+    backward.  Same bars as the default fp32x2 step; the overflow word must stay clear."""
+    from fcd_amd import _lib as L
+    sc, make, b, alpha = full
+    s = make("fp32x2")
+    s.d_scaled_fp16 = True
+    s.set_precision("fp32x2")
+    assert s.D.precision == L.PREC_F16X2
+    s.alpha_override = alpha
+    s.G.requires_grad_(False)
+    s.training_step(b, 0, 0).backward()
+    for k, v in sc["d_losses64"].items():
+        assert abs(float(s.loss_dict[k]) - v) <= 1e-4 * max(1.0, abs(v)), k
+    print("full D-step, D on the fp16 x 2 kernels: worst error / bar =", check_grads(s.D, "d", sc, "fp32x2"))
+    s.check_overflow()
+    s.D.zero_grad(set_to_none=True)
+    s.G.requires_grad_(True)
+    s.D.requires_grad_(False)
+    s.global_step = s.n_critic - 1
+    s.training_step(b, 0, 1).backward()
+    for k, v in sc["g_losses64"].items():
+        assert abs(float(s.loss_dict[k]) - v) <= 1e-4 * max(1.0, abs(v)), k
+    print("full G-step, D on the fp16 x 2 kernels: worst error / bar =", check_grads(s.G, "g", sc, "fp32x2"))
+    s.check_overflow()
+
+
 def test_full_fp16_variant(full):
     """The reduced-precision variant of BASELINE.json configs[1] ("16-bit MFMA"; solver precision 'fp16': scaled fp16
     operands, ONE MFMA per product group in the generator, bf16 operands in the discriminator) at full size: every loss
