@@ -181,13 +181,14 @@ def stream():
 
 
 class _Workspace:
-    """One growing byte buffer per device; all calls are stream-ordered, so it is reused."""
+    """One growing byte buffer per device and stream; calls on one stream are ordered, so it is reused."""
 
     def __init__(self):
         self.buf = {}
 
     def get(self, nbytes: int, device) -> torch.Tensor:
-        key = torch.device(device).index
+        # one buffer per (device, stream): work on the side stream (ops.SideWork) must not share slabs with the chain
+        key = (torch.device(device).index, torch.cuda.current_stream(device).cuda_stream)
         b = self.buf.get(key)
         if b is None or b.numel() < nbytes:
             b = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)

@@ -16,6 +16,7 @@ of elementary ops.
 from __future__ import annotations
 
 import contextlib
+import os
 from typing import List, Optional
 
 import numpy as np
@@ -95,6 +96,7 @@ class Discriminator(nn.Module):
         self.image_size, self.c_dim, self.num_channels = image_size, c_dim, num_channels
         self.precision = L.PREC_F32
         self.wgrad_precision = None          # None: same as precision
+        self.wgrad_side_stream = os.environ.get("FCD_SIDE_STREAM_D", os.environ.get("FCD_SIDE_STREAM", "1")) != "0"   # ops.SideWork
         layers = []
         geoms = []
         cin, cout = num_channels, conv_dim
@@ -213,6 +215,9 @@ class _DBackwardFn(torch.autograd.Function):
         # data parallel: see _GeneratorFn.backward (parameters become final heads first, then layers downwards)
         hook = mod._grad_hook
         final = hook is not None and want_params and hook.pass_begin()
+        side = ops.SideWork(dev, mod.wgrad_side_stream)      # weight / bias gradients beside the data-gradient chain
+        if hook is not None:
+            hook.before_send = side.join
         # heads -> masked gradient at the top activation
         gz = None if only_feat else torch.empty_like(top)
         first = True
@@ -264,10 +269,13 @@ class _DBackwardFn(torch.autograd.Function):
                 wd = g.wgrad_desc(n, a_in.shape[1], a_in.shape[2], precision=prec_w, accumulate=sink is not None)
                 if h2 and prec_w in L.F16_FAMILY:
                     ops.set_wgrad_amax(wd, gamx[li], acts.amx[li])
-                dw = ops.conv_wgrad(wd, gz, a_in, dw=sink)
-                grads[2 * li] = None if sink is not None else dw
                 bsink = grad_sink(cv.bias, gz.shape[3] == g.O)
-                bs = ops.colsum(gz.numel() // gz.shape[3], gz, gz.shape[3], out=bsink, accumulate=bsink is not None)
+                # (results that come back as fresh tensors are sliced below, on this stream: those stay on it)
+                run = side.run if sink is not None and bsink is not None else (lambda fn, *keep: fn())
+                dw, bs = run(lambda: (ops.conv_wgrad(wd, gz, a_in, dw=sink),
+                                      ops.colsum(gz.numel() // gz.shape[3], gz, gz.shape[3], out=bsink,
+                                                 accumulate=bsink is not None)), gz, a_in)
+                grads[2 * li] = None if sink is not None else dw
                 if bsink is None:
                     grads[2 * li + 1] = bs if gz.shape[3] == g.O else bs[: g.O].contiguous()
                 if final:
@@ -289,6 +297,9 @@ class _DBackwardFn(torch.autograd.Function):
                     d.a_amax = gamx[li].data_ptr()
                 ops.set_out_amax(d, gamx[li - 1])
             gz = ops.conv_gather(d, gz, wp, mask=a_in)
+        side.join()
+        if hook is not None:
+            hook.before_send = None
         ctx.mod, ctx.acts, ctx.prec, ctx.gzs = mod, acts, prec, gzs
         ctx.gamx = gamx
         ctx.g_src, ctx.g_cls = g_src, g_cls
@@ -315,6 +326,9 @@ class _DBackwardFn(torch.autograd.Function):
         # first) the spans simply complete in forward order
         hook = mod._grad_hook
         final = hook is not None and any(needs) and hook.pass_begin()
+        side = ops.SideWork(acts[0].device, mod.wgrad_side_stream)
+        if hook is not None:
+            hook.before_send = side.join
         u = ops.nchw_to_nhwc(gg_x.contiguous(), mod._geoms[0].IP)
         gamx = ctx.gamx
         h2 = prec in L.F16_FAMILY and gamx is not None
@@ -331,7 +345,7 @@ class _DBackwardFn(torch.autograd.Function):
                 wd = g.wgrad_desc(n, u.shape[1], u.shape[2], precision=prec_w, accumulate=sink is not None)
                 if h2 and prec_w in L.F16_FAMILY:
                     ops.set_wgrad_amax(wd, gamx[li], uamx[li])
-                dw = ops.conv_wgrad(wd, gzs[li], u, dw=sink)
+                dw = side.run(lambda wd=wd, gz=gzs[li], u=u, sink=sink: ops.conv_wgrad(wd, gz, u, dw=sink), gzs[li], u)
                 out[2 * li] = None if sink is not None else dw
             if needs[2 * li + 1] and grad_sink(mod._convs[li].bias, True) is None:
                 out[2 * li + 1] = torch.zeros_like(mod._convs[li].bias)
@@ -358,6 +372,9 @@ class _DBackwardFn(torch.autograd.Function):
             hook.param_ready(mod.conv1.weight)
             hook.param_ready(mod.conv2.weight)
         # d/d g_src, d/d g_cls (linear) are not needed by the GP: grad_outputs is a constant
+        side.join()
+        if hook is not None:
+            hook.before_send = None
         ctx.gzs = ctx.gamx = None
         return (None,) * 8 + tuple(out)
 

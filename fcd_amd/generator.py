@@ -14,8 +14,9 @@ convolutions, weight gradients as split-K GEMMs).  Activations inside are NHWC.
 """
 from __future__ import annotations
 
-import math
 import contextlib
+import math
+import os
 from typing import List, Optional
 
 import torch
@@ -251,6 +252,7 @@ class Generator(nn.Module):
         self.num_channels, self.activation = num_channels, activation
         self.precision = L.PREC_F32
         self.wgrad_precision = None          # None: same as precision
+        self.wgrad_side_stream = os.environ.get("FCD_SIDE_STREAM", "1") != "0"   # ops.SideWork
         cin = num_channels + c_dim
         mods: List[nn.Module] = []
         plan: List[_Layer] = []
@@ -490,6 +492,9 @@ class _GeneratorFn(torch.autograd.Function):
             return amx[i]
 
         deferred = []          # (s12, dgamma sink, dbeta sink) of the norms whose affine gradients are summed at the end
+        side = ops.SideWork(x.device, mod.wgrad_side_stream)
+        if hook is not None:
+            hook.before_send = side.join
         for li in range(len(plan) - 1, -1, -1):
             ly = plan[li]
             z, mean, rstd, use_running = saved[li]
@@ -544,12 +549,12 @@ class _GeneratorFn(torch.autograd.Function):
                     wd = gm.wgrad_desc(n, a_in.shape[1], a_in.shape[2], precision=prec_w, accumulate=sink is not None)
                     if h2_w:
                         ops.set_wgrad_amax(wd, dz_amax(), act_amax(li))
-                    dw = ops.conv_wgrad(wd, dz, a_in, dw=sink)
+                    dw = side.run(lambda: ops.conv_wgrad(wd, dz, a_in, dw=sink), dz, a_in)
                 else:
                     wd = gm.wgrad_desc(n, dz.shape[1], dz.shape[2], precision=prec_w, accumulate=sink is not None)
                     if h2_w:
                         ops.set_wgrad_amax(wd, act_amax(li), dz_amax())
-                    dw = ops.conv_wgrad(wd, a_in, dz, dw=sink)
+                    dw = side.run(lambda: ops.conv_wgrad(wd, a_in, dz, dw=sink), dz, a_in)
                 if sink is None:
                     grads[p0] = dw
             if final:
@@ -579,5 +584,8 @@ class _GeneratorFn(torch.autograd.Function):
                 g = ops.conv_gather(d, dz, wa, residual=res)
         if deferred:
             ops.instnorm_affine_batch(deferred, accumulate=True)
+        side.join()
+        if hook is not None:
+            hook.before_send = None
         ctx.acts = ctx.saved_layers = None
         return (None, gx, None) + tuple(grads)

@@ -32,6 +32,44 @@ def _ws(nbytes: int, device):
     return b.data_ptr(), b.numel()
 
 
+_SIDE = {}
+
+
+class SideWork:
+    """Weight gradients beside the data-gradient chain: a backward pass is a chain dz -> dgrad -> norm backward -> dz
+    with one weight gradient hanging off every link; nothing in the pass reads those, so they go to a second HIP
+    stream, where their bandwidth-bound tails (slab reductions) and the chain's bandwidth-bound links (norm backward)
+    fill each other's idle matrix pipes.  ``run`` orders the side stream behind everything enqueued so far on the
+    current one; ``join`` orders the current stream behind the side work (before the gradients are read: optimizer,
+    all-reduce) and lets go of the operands kept alive for it."""
+
+    def __init__(self, device, enabled: bool = True):
+        self.side = None
+        if enabled and torch.device(device).type == "cuda":
+            key = torch.device(device).index
+            if key not in _SIDE:
+                _SIDE[key] = torch.cuda.Stream(device=device)
+            self.side = _SIDE[key]
+        self.keep = []
+        self.dirty = False
+
+    def run(self, fn, *operands):
+        if self.side is None:
+            return fn()
+        self.side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.side):
+            r = fn()
+        self.keep.extend(operands)
+        self.dirty = True
+        return r
+
+    def join(self) -> None:
+        if self.dirty:
+            torch.cuda.current_stream().wait_stream(self.side)
+            self.dirty = False
+        self.keep.clear()
+
+
 # --------------------------------------------------------------------------- #
 # convolution geometry (host logic; unit-tested on CPU)
 # --------------------------------------------------------------------------- #

@@ -208,6 +208,7 @@ class BucketedReducer:
 
     def __init__(self, sync: GradSync, arena, bucket_elems: int):
         self.sync, self.arena, self.bucket_elems = sync, arena, max(1, int(bucket_elems))
+        self.before_send = None
         n = len(arena.params)
         ends = list(arena.offsets[1:]) + [arena.flat.numel()]
         self.spans = []                 # (lo, hi) element ranges, last span of the arena first
@@ -250,6 +251,8 @@ class BucketedReducer:
     def _fire(self, si: int) -> None:
         lo, hi = self.spans[si]
         self.fired[si] = True
+        if self.before_send is not None:       # gradient kernels on a side stream (ops.SideWork): order this one behind them
+            self.before_send()
         for off in range(lo, hi, self.bucket_elems):
             self.handle += self.sync.allreduce_flat_async(self.arena.grad[off:min(hi, off + self.bucket_elems)])
 

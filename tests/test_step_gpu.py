@@ -244,6 +244,27 @@ def test_shared_generator_forward_equals_reference_sequence(dev, tiny, prec):
     assert worst <= 5e-3                  # Adam's first steps are ~lr * sign(g): rounding-level gradients may flip
 
 
+@pytest.mark.parametrize("prec", ["fp32", "fp32x2"])
+def test_side_stream_weight_gradients_are_the_same_bits(dev, tiny, prec):
+    """The weight gradients run on a second HIP stream beside the data-gradient chain (ops.SideWork); the same kernels
+    accumulate into the same arena in the same order, so three steps must leave the same bits in every weight and
+    running statistic as the one-stream order."""
+    z, sc = tiny
+    states = {}
+    for side in (True, False):
+        s = build(z, sc["cfg"], dev)
+        s.set_precision(prec)
+        s.G.wgrad_side_stream = s.D.wgrad_side_stream = side
+        s.alpha_override = torch.from_numpy(z["alpha"])
+        b = batch_of(z, dev)
+        for _ in range(3):
+            s.train_step(b, force_g=True)
+        torch.cuda.synchronize()
+        states[side] = {k: v.detach().clone() for k, v in s.state_dict().items()}
+    for k, v in states[False].items():
+        assert torch.equal(states[True][k], v), k
+
+
 def test_arena_gradients_match_fixtures(dev, tiny):
     """Same D-step gradients when the backward kernels accumulate straight into the gradient
     arena (the training path) instead of going through autograd (the other tests)."""
