@@ -149,20 +149,20 @@ def pmc_traffic(label, symbol):
     the counter tallies 128-byte requests at 64 bytes) + WRITE_SIZE, both in KB.  The kernel is looked up by the
     symbol this run really launched (fcd_last_conv_kernel); if the profile does not hold that symbol -- the kernel
     changed since the profile was taken -- there is no figure, and the reason is reported instead of a stale one."""
-    path = os.path.join(ROOT, "profiles", "r2_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r3_traffic.json")
     try:
         table = json.load(open(path))[label]
     except (OSError, KeyError, ValueError) as e:
-        return None, f"no traffic profile for {label!r} in profiles/r2_traffic.json ({type(e).__name__})"
+        return None, f"no traffic profile for {label!r} in profiles/r3_traffic.json ({type(e).__name__})"
     hit = table.get(symbol)
     if hit is None:
-        return None, (f"profiles/r2_traffic.json[{label!r}] has no kernel {symbol!r} (it holds {sorted(table)}): "
+        return None, (f"profiles/r3_traffic.json[{label!r}] has no kernel {symbol!r} (it holds {sorted(table)}): "
                       "re-run tools/prof_traffic.sh for the current kernels")
     return int(2 * hit["fetch_size_kb"] * 1024 + hit["write_size_kb"] * 1024), \
         f"{hit['files'][0]}, {hit['files'][1]}: FETCH_SIZE {hit['fetch_size_kb']:.0f} KB x 2 + WRITE_SIZE {hit['write_size_kb']:.0f} KB"
 
 
-def dominant_kernel_roofline(precision, dev, in_step_us=None, in_step_launches=0, iters=20, symbol=None):
+def dominant_kernel_roofline(precision, dev, in_step_us=None, in_step_launches=0, iters=20, symbol=None, overlapped_us=None):
     """The hottest kernel: 3x3 s1 256->256 conv at 32x32 on 32 samples (the G step pairs the reference's
     B=16 generator calls; forward form; dgrad runs the same kernel with flipped taps).  FLOPs per launch
     = 2*32*Cin*Cout*9*H*W.  `achieved` uses the
@@ -239,11 +239,19 @@ def dominant_kernel_roofline(precision, dev, in_step_us=None, in_step_launches=0
             "note": "every launch of this kernel symbol in 2 training steps (all layer shapes; "
                     "launches with fused InstanceNorm statistics include their ~6 us finalize kernel): compare "
                     "with the per-kernel average of profiles/*_kernel_stats.csv"}
+    if overlapped_us:
+        ach_ov = flops / (overlapped_us * 1e-6) / 1e12
+        extra["overlapped"] = {
+            "us_per_launch": round(overlapped_us, 2), "achieved": round(ach_ov, 2), "frac": round(ach_ov / peak, 4),
+            "note": "the same launches in two steps as `value` runs them: weight gradients on a second HIP stream, so the "
+                    "data-gradient half of these launches shares the CUs with a weight-gradient kernel (longer launches, "
+                    "shorter step); kernel durations of such a step overlap and do not add up to the step time"}
     return {**extra, "bound": "mfma", "kernel": launched + " 3x3 256->256 @32x32, 32 samples per launch (two paired B=16 calls)",
             "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
             "us_per_launch": round(ms * 1e3, 2), "launches_timed": in_step_launches,
             "timed": "HIP events around every launch of this kernel in 2 training steps run right after the timed "
-                     "region (an event pair per launch slows the step ~14 %, so they stay out of `value`)" if in_step_us
+                     "region with the weight-gradient side stream off, i.e. every launch alone on the device (an event "
+                     "pair per launch slows the step ~14 %, so they stay out of `value`)" if in_step_us
             else "back-to-back loop", "us_per_launch_back_to_back_loop": round(loop_us, 2),
             "gflop_per_launch": round(flops / 1e9, 3),
             "engine_clock_mhz_under_kernel": sclk, "engine_clock_mhz_nominal": 2400,
@@ -528,9 +536,21 @@ def main():
     # The dominant kernel's duration inside real training steps: HIP events around each of its
     # launches in two more steps of the same loop.  Kept out of the timed region above because an
     # event pair per launch (108 per step) costs the step ~14 %.
-    timer = ops.KernelTimer(is_dominant)
+    # Since round 3 the weight gradients run on a second stream (ops.SideWork), so in the step as timed above half of
+    # this kernel's launches (the data gradients) share the CUs with a weight gradient and take longer while the step
+    # gets shorter.  A kernel's roofline is about the kernel: `roofline.frac` comes from two steps with the second
+    # stream off (every launch alone on the device, as in rounds 1-2); the same two steps with it on are reported
+    # beside it (`roofline.overlapped`).
+    timer, timer_ov = ops.KernelTimer(is_dominant), ops.KernelTimer(is_dominant)
+    side = (solver.G.wgrad_side_stream, solver.D.wgrad_side_stream)
     if world == 1:
+        solver.G.wgrad_side_stream = solver.D.wgrad_side_stream = False
         ops.KERNEL_TIMER = timer
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        solver.G.wgrad_side_stream, solver.D.wgrad_side_stream = side
+        ops.KERNEL_TIMER = timer_ov
         for _ in range(2):
             step()
         torch.cuda.synchronize()
@@ -636,7 +656,8 @@ def main():
                                 "sclk_mhz": sus_clk["sclk_mhz"], "socket_watts": sus_clk["socket_watts"]}
         extra_leg(res, "roofline", lambda: dominant_kernel_roofline(
             args.precision, dev, timer.mean_us("dominant") if timer.pairs else None, timer.count("dominant"),
-            symbol=timer.total() if timer.pairs else None))
+            symbol=timer.total() if timer.pairs else None,
+            overlapped_us=timer_ov.mean_us("dominant") if timer_ov.pairs and any(side) else None))
         if world == 1:
             # the same step with the reference's literal call sequence: G(x_real, c_trg) computed in the D step AND
             # again in the G step, and the D(x_reconst_id) forward whose outputs nothing reads (fcd_solver.py:291, 316, 358)
