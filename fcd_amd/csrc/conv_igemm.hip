@@ -364,7 +364,16 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 // instead of once per wave), 16-byte chunk slot XOR ((pixel >> 2) & 3) keeps the shifted reads conflict-free.
 constexpr int ah_maxpx(int bm) { return bm == 256 ? 396 : 264; }   // (4 + 2) x 66 or 10 x 34 halo pixels; 128 rows: 4 x 66 or 6 x 34
 
-template <int BM, int BN, int WM, int WN, int S, int PREC, bool N16 = false, bool BPRE = false, bool AH = false, int NP = 3>
+// RS ("register-staged", FCD_PREC_BF16X3 with fp32 weights, 32-channel K slices, BN = 128, 8 waves, two stages): neither
+// operand travels by LDS-DMA.  Per K-tile (one tap of a 32-channel slice) the BM x 32 activation values and the 128 x 32
+// weight values go global -> registers, are split ONCE per workgroup into NP planes [row][32 k] in LDS (64-byte rows,
+// chunk slot XOR (row >> 2) & 3), and every wave reads ready-made fragments: the in-register-split form above splits each
+// activation fragment once per wave column and each weight fragment once per wave row (6 x the values of a 128 x 128
+// tile with 2 x 4 waves), which is what bounds the discriminator's deep layers (few output rows, K = 4096 .. 16384).
+// Same pieces, same products in the same order per accumulator: bit-identical to that form.  With both maxima
+// attached (FCD_PREC_F16X2 / _F16, weight format 3) the pieces are two / one scaled fp16 ones.
+template <int BM, int BN, int WM, int WN, int S, int PREC, bool N16 = false, bool BPRE = false, bool AH = false, int NP = 3,
+          bool RS = false>
 __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const GatherArgs p, const size_t in_bytes,
                                                                        const unsigned w_bytes) {
   static_assert(!N16 || (BN == 32 && WN == 1 && PREC == FCD_PREC_F32), "N16 shape");
@@ -376,11 +385,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
   static_assert(!BPRE || (PREC == FCD_PREC_BF16X3 && BN % 16 == 0 && !N16), "BPRE shape");
   // BPRE: a B row is 3 planes x 4 chunks (32 bf16 each); one DMA instruction ("unit") covers 16 rows of
   // a plane; units past 3*BN/16 (BN = 64: 12 units on 8 waves) are all-out-of-range dummies
-  static_assert(NP == 3 || ((NP == 2 || NP == 1) && BPRE), "fp16 planes (two: FCD_PREC_F16X2, one: FCD_PREC_F16): pre-split weights only");
+  static_assert(NP == 3 || ((NP == 2 || NP == 1) && (BPRE || RS)), "fp16 planes (two: FCD_PREC_F16X2, one: FCD_PREC_F16): pre-split weights or the register-staged form");
+  static_assert(!RS || (!BPRE && !AH && !N16 && PREC == FCD_PREC_BF16X3 && WM * WN == 8 && BN == 128 && S == 2 && (BM == 128 || BM == 64)), "RS shape");
   constexpr int BUNITS = NP * BN / 16;
-  constexpr int AL = AH ? 0 : BM / RPI, BL = BPRE ? (BUNITS + NW - 1) / NW : BN / RPI;   // DMA instructions per wave per K-tile
+  constexpr int AL = (AH || RS) ? 0 : BM / RPI, BL = RS ? 0 : BPRE ? (BUNITS + NW - 1) / NW : BN / RPI;   // DMA instructions per wave per K-tile
   constexpr int AOFF = AH ? 0 : BM * 8;                            // float4 chunks of a stage's activation part
-  constexpr int STAGE = AOFF + (BPRE ? BL * NW * 64 : BN * 8);     // float4 chunks per stage
+  constexpr int STAGE = RS ? NP * (BM + BN) * 4 : AOFF + (BPRE ? BL * NW * 64 : BN * 8);     // float4 chunks per stage
   static_assert((NW == 4 || NW == 8) && S >= 2 && BM % RPI == 0 && BN % RPI == 0 && TM >= 1 && TN >= 1, "shape");
   static_assert(!AH || (BPRE && (BM == 256 || BM == 128) && NW == 8 && S == 3), "AH shape");
   constexpr int AH_MAXPX = ah_maxpx(BM);
@@ -439,7 +449,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
       for (int t = 0; t < p.KW; ++t) a_mw[i] |= (unsigned)(iw0 + t >= 0 && iw0 + t < p.IW) << t;
     }
   }
-  unsigned b_base[BL];
+  unsigned b_base[BL > 0 ? BL : 1];
   if constexpr (BPRE) {
     // instruction ii = wave + NW*i of the tile: plane = ii / (BN/16), rows 16*(ii % (BN/16)) + (lane>>2),
     // slot lane&3 holds chunk slot ^ ((row>>2)&3) (8 bf16 = 16 bytes per chunk)
@@ -562,7 +572,177 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
   const int lr = lane & 31, lh = lane >> 5;
   const int lr16 = lane & 15, lg = lane >> 4;
 
-  if constexpr (PREC == FCD_PREC_BF16X3 && !N16 && (S == 3 || S == 2)) {
+  if constexpr (RS) {
+    constexpr int A_F4 = BM * 8 / NT, B_F4 = BN * 8 / NT;       // float4 of a K-tile per thread: 2 + 2 (BM = 128), 1 + 2 (BM = 64)
+    constexpr int A_PL = BM * 64, B_PL = BN * 64;               // bytes per plane: 64 per row (32 k x 2 bytes)
+    constexpr int STG = NP * (A_PL + B_PL);
+    static_assert(STG == STAGE * 16 && A_F4 >= 1 && B_F4 >= 1, "RS stage");
+    unsigned char* const sm = reinterpret_cast<unsigned char*>(smem);
+    float a_scale = 1.f, w_scale = 1.f, om = 0.f;
+    if constexpr (NP <= 2) { a_scale = pow2_scale(p.a_amax); w_scale = pow2_scale(p.w_amax); }
+    __amdgpu_buffer_rsrc_t rinb = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(p.in)) + in_start, (short)0, (int)window_bytes(in_bytes, in_start), 0x00020000);
+    __amdgpu_buffer_rsrc_t rwb = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(p.w + (long)phase * p.w_phase_stride)), (short)0, (int)w_bytes, 0x00020000);
+    // this thread's float4: row (tid >> 3) + 64 j of the tile, channels / k 4 (tid & 7) .. of the K-tile
+    const int c4 = tid & 7;
+    int ra_base[A_F4];
+    unsigned ra_mh[A_F4], ra_mw[A_F4], a_st[A_F4], rb_base[B_F4], b_st[B_F4];
+#pragma unroll
+    for (int j = 0; j < A_F4; ++j) {
+      const int row = (tid >> 3) + 64 * j, m = tm * BM + row;
+      ra_base[j] = 0;
+      ra_mh[j] = ra_mw[j] = 0u;
+      if (m < p.M) {
+        const int n = m / ghw, rem = m - n * ghw;
+        const int a = rem / p.GW, b = rem - a * p.GW;
+        const int ih0 = a * p.istride - pad_h, iw0 = b * p.istride - pad_w;
+        ra_base[j] = ((((n - n0) * p.IH + ih0) * p.IW + iw0) * p.Cin + c4 * 4) * 4;
+        for (int t = 0; t < p.KH; ++t) ra_mh[j] |= (unsigned)(ih0 + t >= 0 && ih0 + t < p.IH) << t;
+        for (int t = 0; t < p.KW; ++t) ra_mw[j] |= (unsigned)(iw0 + t >= 0 && iw0 + t < p.IW) << t;
+      }
+      a_st[j] = (unsigned)(row * 64 + (((c4 >> 1) ^ ((row >> 2) & 3)) << 4) + 8 * (c4 & 1));
+    }
+#pragma unroll
+    for (int j = 0; j < B_F4; ++j) {
+      const int row = (tid >> 3) + 64 * j, co = tn * BN + row;
+      rb_base[j] = co < p.Cout ? (unsigned)(((long)co * p.K + c4 * 4) * 4) : OOB;
+      b_st[j] = (unsigned)(NP * A_PL + row * 64 + (((c4 >> 1) ^ ((row >> 2) & 3)) << 4) + 8 * (c4 & 1));
+    }
+    // the K-tile the NEXT load fetches (wave-uniform): tap (lth, ltw) of channel slice lcs / 32; lk = tap * Cin + lcs
+    int lt = 0, lth = (kt0 % T) / p.KW, ltw = (kt0 % T) % p.KW, lcs = (kt0 / T) * 32, lk = (kt0 % T) * p.Cin + lcs;
+    u32x4 ra[A_F4], rb[B_F4];
+    auto load_item = [&](int q_) {
+      const unsigned live = lt < nk ? 0xFFFFFFFFu : 0u;
+      if (q_ < A_F4) {
+        const unsigned okm = (0u - ((ra_mh[q_] >> lth) & (ra_mw[q_] >> ltw) & 1u)) & live;
+        const unsigned voff = (((unsigned)ra_base[q_] + (unsigned)(((lth * p.IW + ltw) * p.Cin + lcs) * 4)) & okm) | (OOB & ~okm);
+        ra[q_] = __builtin_amdgcn_raw_buffer_load_b128(rinb, (int)voff, 0, 0);
+      } else {
+        const unsigned voff = (rb_base[q_ - A_F4] + (unsigned)(lk * 4)) | (OOB & ~live);     // rows past Cout stay >= OOB
+        rb[q_ - A_F4] = __builtin_amdgcn_raw_buffer_load_b128(rwb, (int)voff, 0, 0);
+      }
+      if (q_ == A_F4 + B_F4 - 1) {            // all items of the tile issued: on to the next tap / slice (branch-free)
+        ++lt;
+        lk += p.Cin;
+        ltw += 1;
+        const bool ww = ltw == p.KW;
+        ltw = ww ? 0 : ltw;
+        lth += ww ? 1 : 0;
+        const bool wh = lth == p.KH;
+        lth = wh ? 0 : lth;
+        lcs += wh ? 32 : 0;
+        lk += wh ? 32 - T * p.Cin : 0;
+      }
+    };
+    auto split_store = [&](const u32x4 v, unsigned char* dst, int plane_bytes, float sc) {
+      if constexpr (NP == 1) {
+        uint2 h2;
+        cvt4_f16(v, sc, h2, om);
+        *reinterpret_cast<uint2*>(dst) = h2;
+      } else if constexpr (NP == 2) {
+        uint2 h2, l2;
+        split2_f16(v, sc, h2, l2, om);
+        *reinterpret_cast<uint2*>(dst) = h2;
+        *reinterpret_cast<uint2*>(dst + plane_bytes) = l2;
+      } else {
+        const float f0 = __uint_as_float(v.x), f1 = __uint_as_float(v.y), f2 = __uint_as_float(v.z), f3 = __uint_as_float(v.w);
+        const unsigned h0 = cvt_pk_bf16(f0, f1), h1 = cvt_pk_bf16(f2, f3);
+        const float r0 = f0 - __uint_as_float(h0 << 16), r1 = f1 - __uint_as_float(h0 & 0xFFFF0000u);
+        const float r2 = f2 - __uint_as_float(h1 << 16), r3 = f3 - __uint_as_float(h1 & 0xFFFF0000u);
+        const unsigned m0 = cvt_pk_bf16(r0, r1), m1 = cvt_pk_bf16(r2, r3);
+        const float s0 = r0 - __uint_as_float(m0 << 16), s1 = r1 - __uint_as_float(m0 & 0xFFFF0000u);
+        const float s2 = r2 - __uint_as_float(m1 << 16), s3 = r3 - __uint_as_float(m1 & 0xFFFF0000u);
+        *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(dst + plane_bytes) = make_uint2(m0, m1);
+        *reinterpret_cast<uint2*>(dst + 2 * plane_bytes) = make_uint2(cvt_pk_bf16(s0, s1), cvt_pk_bf16(s2, s3));
+      }
+    };
+    auto store_item = [&](int q_, unsigned char* base) {
+      if (q_ < A_F4) split_store(ra[q_], base + a_st[q_], A_PL, a_scale);
+      else split_store(rb[q_ - A_F4], base + b_st[q_ - A_F4], B_PL, w_scale);
+    };
+    // fragment addresses inside a stage: row r, 16-byte chunk 2 s2 + lh of its 64 bytes
+    unsigned a_rd[TM][2], b_rd[TN][2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi) {
+        const int r = wm * WTM + mi * 32 + lr;
+        a_rd[mi][s2] = (unsigned)(r * 64 + (((2 * s2 + lh) ^ ((r >> 2) & 3)) << 4));
+      }
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni) {
+        const int r = wn * WTN + ni * 32 + lr;
+        b_rd[ni][s2] = (unsigned)(NP * A_PL + r * 64 + (((2 * s2 + lh) ^ ((r >> 2) & 3)) << 4));
+      }
+    }
+    constexpr int NI = A_F4 + B_F4;
+    if (nk > 0) {
+#pragma unroll
+      for (int q_ = 0; q_ < NI; ++q_) load_item(q_);
+#pragma unroll
+      for (int q_ = 0; q_ < NI; ++q_) store_item(q_, sm);
+#pragma unroll
+      for (int q_ = 0; q_ < NI; ++q_) load_item(q_);      // tile 1 (zeros past the end of this block's K range)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    constexpr int NPR = NP == 3 ? 6 : (NP == 2 ? 3 : 1);   // products per group
+    constexpr int NMF = 2 * NPR * TM * TN;                 // MFMAs per K-tile
+    for (int it = 0; it < nk; ++it) {
+      const unsigned char* cur = sm + (it & 1) * STG;
+      unsigned char* nxt = sm + ((it + 1) & 1) * STG;
+      // among the MFMAs of tile it: tile it+1 goes registers -> planes of the other stage (the barrier below ended the
+      // reads of it), item by item, and each freed register takes its piece of tile it+2; one basic block
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        bf16x8_t ah[TM], am[TM], al[TM], bh[TN], bm2[TN], bl[TN];
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+          ah[mi] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(cur + a_rd[mi][s2]));
+          if constexpr (NP == 3) am[mi] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(cur + a_rd[mi][s2] + A_PL));
+          if constexpr (NP >= 2) al[mi] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(cur + a_rd[mi][s2] + (NP - 1) * A_PL));
+        }
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+          bh[ni] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(cur + b_rd[ni][s2]));
+          if constexpr (NP == 3) bm2[ni] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(cur + b_rd[ni][s2] + B_PL));
+          if constexpr (NP >= 2) bl[ni] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(cur + b_rd[ni][s2] + (NP - 1) * B_PL));
+        }
+#pragma unroll
+        for (int pc = 0; pc < NPR; ++pc)
+#pragma unroll
+          for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+              if constexpr (NP <= 2) {
+                const int pq = NP == 1 ? 2 : pc;      // al.bh, ah.bl into the side accumulator, ah.bh into the main one
+                const f16x8_t a = __builtin_bit_cast(f16x8_t, pq == 0 ? al[mi] : ah[mi]);
+                const f16x8_t b = __builtin_bit_cast(f16x8_t, pq == 1 ? bl[ni] : bh[ni]);
+                if (pq < 2) acc2[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc2[mi][ni], 0, 0, 0);
+                else acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[mi][ni], 0, 0, 0);
+              } else {
+                const bf16x8_t a = pc == 0 ? al[mi] : (pc == 2 || pc == 3) ? am[mi] : ah[mi];
+                const bf16x8_t b = pc == 1 ? bl[ni] : (pc == 2 || pc == 4) ? bm2[ni] : bh[ni];
+                if (pc < 5) acc2[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc2[mi][ni], 0, 0, 0);
+                else acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[mi][ni], 0, 0, 0);
+              }
+              const int g = ((s2 * NPR + pc) * TM + mi) * TN + ni;     // 0 .. NMF-1
+#pragma unroll
+              for (int q_ = 0; q_ < NI; ++q_) {
+                // (slots clamped to the last MFMA: with few MFMAs per K-tile they would fall past the end)
+                constexpr int LD_OFF = NMF / (2 * NI) + 1;
+                if ((q_ * NMF / NI + 1 < NMF ? q_ * NMF / NI + 1 : NMF - 1) == g) store_item(q_, nxt);
+                if ((q_ * NMF / NI + LD_OFF < NMF ? q_ * NMF / NI + LD_OFF : NMF - 1) == g) load_item(q_);
+              }
+            }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    if constexpr (NP <= 2) ovf_report(om, p.ovf);
+  } else if constexpr (PREC == FCD_PREC_BF16X3 && !N16 && (S == 3 || S == 2)) {
     // Software-pipelined BF16X3 loop: the split of k16-step i+1 (VALU) is issued among the MFMAs of
     // step i, so the two pipes overlap inside a wave instead of alternating.  Tiles are fetched three
     // ahead; the one barrier per K-tile sits between the two k16-steps: by then every wave has read
@@ -3286,6 +3466,14 @@ bool gather_big_tile(const FcdConvDesc* d) {
   return (long)fcd_cdiv(M, 256) * fcd_cdiv(d->Cout, bn) * d->nphase >= 256;
 }
 
+// The register-staged form (template flag RS) of the FCD_PREC_BF16X3 kernels that take fp32 weights: 128- or 64-row
+// tiles of 128 output channels on 32-channel K slices -- the discriminator's deep layers (fewer than 2100 output rows,
+// up to 134 MB of weights).  FCD_NO_RS=1 keeps the in-register-split form (A/B runs; same bits).
+bool gather_rs(const FcdConvDesc* d, int bm, int bn) {
+  if (getenv("FCD_NO_RS")) return false;
+  return d->precision == FCD_PREC_BF16X3 && d->Cin % 32 == 0 && bn == 128 && (bm == 128 || bm == 64);
+}
+
 // The A-halo form of the pre-split 256x128 / 128x128 kernels (template flag AH): 3x3, stride 1, pad 1, one phase, no
 // split-K, image width 32 or 64 and a height that keeps the tiles (`rows` output rows) inside one image.
 bool gather_ahalo(const FcdConvDesc* d, int rows) {
@@ -3455,7 +3643,30 @@ int run_gather(const FcdConvDesc* d, GatherArgs& a, hipStream_t st) {
     rc = fcd_check_launch("conv_gather");
   } else {
     if (want_amax && a.splitk == 1) { a.out_amax = want_amax; a.out_amax_in_kernel = 1; }
-    if (bm == 128 && bn == 32) rc = launch_gather<128, 32, 4, 1>(a, d->precision, st);
+    if (gather_rs(d, bm, bn)) {
+      // both operands split once per workgroup (fp32 weights; two / one scaled fp16 pieces when both maxima are attached)
+      const int np = (a.a_amax && a.w_amax) ? (a.onep ? 1 : 2) : 3;
+      dim3 grid(a.tiles_m * a.tiles_n, a.nphase * a.splitk);
+      const size_t in_bytes = (size_t)a.N * a.IH * a.IW * a.Cin * 4;
+      const unsigned w_bytes = (unsigned)((size_t)a.Cout * a.K * 4);
+      constexpr int X3 = FCD_PREC_BF16X3;
+      note_kernel("conv_gather_dma_kernel<%d, 128, %d, %d, 2, 2, false, false, false, %d, true>", bm, bm == 128 ? 4 : 2, bm == 128 ? 2 : 4, np);
+#define FCD_LAUNCH_RS(NP_)                                                                                                     \
+  do {                                                                                                                        \
+    if (bm == 128)                                                                                                            \
+      hipLaunchKernelGGL((conv_gather_dma_kernel<128, 128, 4, 2, 2, X3, false, false, false, NP_, true>), grid, dim3(512), 0, \
+                         st, a, in_bytes, w_bytes);                                                                           \
+    else                                                                                                                      \
+      hipLaunchKernelGGL((conv_gather_dma_kernel<64, 128, 2, 4, 2, X3, false, false, false, NP_, true>), grid, dim3(512), 0,  \
+                         st, a, in_bytes, w_bytes);                                                                           \
+  } while (0)
+      if (np == 1) FCD_LAUNCH_RS(1);
+      else if (np == 2) FCD_LAUNCH_RS(2);
+      else FCD_LAUNCH_RS(3);
+#undef FCD_LAUNCH_RS
+      rc = fcd_check_launch("conv_gather");
+    }
+    else if (bm == 128 && bn == 32) rc = launch_gather<128, 32, 4, 1>(a, d->precision, st);
     else if (bm == 128 && bn == 64) rc = launch_gather<128, 64, 4, 2>(a, d->precision, st);
     else if (bm == 64 && bn == 128) rc = launch_gather<64, 128, 2, 4>(a, d->precision, st);
     else if (bm == 64 && bn == 64) rc = launch_gather<64, 64, 2, 2>(a, d->precision, st);
@@ -3481,7 +3692,7 @@ int fused_stats_chunks(const FcdConvDesc* d) {
   gather_tile(d, bm, bn);
   if (bn == 16 || resolve_splitk(d) != 1) return 0;
   // rows per wave: the pre-split kernels run 4 x 2 waves on 128 rows, 4 x 2 or 8 x 1 on 256
-  const int wtm = (gather_big_tile(d) && bn == 128) ? 64 : wants_split_weights(d) ? 32 : gather_wave_rows(bm, bn);
+  const int wtm = (gather_big_tile(d) && bn == 128) ? 64 : wants_split_weights(d) ? 32 : gather_rs(d, bm, bn) ? 32 : gather_wave_rows(bm, bn);
   const long ghw = (long)d->GH * d->GW;
   if (ghw % wtm) return 0;
   return (int)(d->nphase * (ghw / wtm));
@@ -3510,7 +3721,10 @@ NormDesc normalise(const FcdConvDesc* d) {
       } else {
         GatherArgs plain{};
         plain.splitk = 1;
-        n.h2opt = halo12_rows(&n.d, nullptr) > 0 || (halo7_fwd_rows(&n.d, plain) > 0 && n.d.CoutP % 4 == 0);
+        int bm, bn;
+        gather_tile(&n.d, bm, bn);
+        n.h2opt = halo12_rows(&n.d, nullptr) > 0 || (halo7_fwd_rows(&n.d, plain) > 0 && n.d.CoutP % 4 == 0) ||
+                  gather_rs(&n.d, bm, bn);
       }
     }
   }

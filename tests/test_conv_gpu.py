@@ -986,3 +986,91 @@ def test_f16x2_overflow_guard(dev):
     with pytest.raises(RuntimeError, match="overflow guard"):
         s.state_dict()
     s.state_dict()
+
+
+# (O, I, N, small H, small W, form): 4x4 stride-2 layers with few output rows (the discriminator's deep layers), ragged
+# channel counts and row counts, split-K, the four-phase adjoint
+RS_GEOMS = [
+    (512, 256, 32, 8, 8, "fwd"),       # 128-row tiles, split-K 4
+    (1024, 512, 16, 4, 4, "fwd"),      # M = 256
+    (2048, 1024, 4, 2, 2, "fwd"),      # 64-row tile, 16 rows of it used
+    (1024, 512, 9, 4, 4, "adj"),       # four phases, M = 144 per phase
+    (200, 96, 5, 6, 7, "fwd"),         # ragged: 200 output channels (two column tiles), 210 rows
+    (160, 136, 3, 5, 3, "adj"),        # ragged adjoint: 136 output channels, 45 rows per phase (64-row tile)
+]
+
+
+@pytest.mark.parametrize("geom", RS_GEOMS)
+def test_gather_register_staged_equals_in_register_split(dev, geom, monkeypatch):
+    """The register-staged form of the BF16X3 gather kernel with fp32 weights (template flag RS: both operands go
+    global -> registers, are split once per workgroup into planes in LDS) produces the same bits as the form that
+    splits every fragment in registers (FCD_NO_RS=1), epilogue operands, split-K and maximum of the output included."""
+    from fcd_amd import _lib as L, ops
+    O, I, N, H, W, form = geom
+    g = ops.ConvGeom(O, I, 4, 2, 1)
+    gen = torch.Generator().manual_seed(77)
+    wd = (torch.randn(O, I, 4, 4, generator=gen) / (4 * I ** 0.5)).to(dev)
+    if form == "fwd":
+        xd = to_nhwc(torch.randn(N, I, 2 * H, 2 * W, generator=gen), g.IP).to(dev)
+        mk = lambda: g.fwd_desc(N, 2 * H, 2 * W, precision=2, act_slope=0.01, mask_slope=0.3)
+        oshape, oc = (N, H, W, g.OP), O
+        wp = ops.pack_weight_fwd(wd, g)
+    else:
+        xd = to_nhwc(torch.randn(N, O, H, W, generator=gen), g.OP).to(dev)
+        mk = lambda: g.adj_desc(N, H, W, precision=2, mask_slope=0.3)
+        oshape, oc = (N, 2 * H, 2 * W, g.IP), I
+        wp = ops.pack_weight_adj(wd, g)
+    assert ops.weight_format(mk()) == 0
+    bias = torch.randn(oc, generator=gen).to(dev)
+    mask = torch.randn(*oshape, generator=gen).to(dev)
+    res = torch.randn(*oshape, generator=gen).to(dev)
+    outs = {}
+    for mode in ("rs", "split"):
+        if mode == "split":
+            monkeypatch.setenv("FCD_NO_RS", "1")
+        for sk in (0, 3):
+            d = mk()
+            d.splitk = sk
+            am = torch.zeros(ops.AMAX_SLOTS, device=dev)
+            ops.set_out_amax(d, am)
+            outs[mode, sk] = (ops.conv_gather(d, xd, wp, bias=bias, mask=mask, residual=res), float(am.max()))
+            kern = L.load().fcd_last_conv_kernel()
+            assert kern.endswith(b"true>") == (mode == "rs"), kern
+    for sk in (0, 3):
+        assert torch.equal(outs["rs", sk][0], outs["split", sk][0])
+        assert outs["rs", sk][1] == outs["split", sk][1] == float(outs["rs", sk][0].abs().max())
+
+
+@pytest.mark.parametrize("fam", F16_FAM)
+@pytest.mark.parametrize("geom", [(512, 256, 32, 8, 8, "fwd", 1.0), (2048, 1024, 16, 2, 2, "fwd", 3e-5),
+                                  (1024, 512, 9, 4, 4, "adj", 200.0), (200, 96, 5, 6, 7, "fwd", 1.0)])
+def test_gather_register_staged_f16x2(dev, fam, geom):
+    """The register-staged form under FCD_PREC_F16X2 / _F16 (weight format 3: fp32 weights, both operands scaled and
+    split into fp16 pieces inside the kernel when both maxima are attached): <= 1e-6 (fp32x2) / 1e-3 (fp16) of torch in
+    float64."""
+    from fcd_amd import _lib as L, ops
+    O, I, N, H, W, form, sc = geom
+    g = ops.ConvGeom(O, I, 4, 2, 1)
+    gen = torch.Generator().manual_seed(78)
+    wt = torch.randn(O, I, 4, 4, generator=gen) / (4 * I ** 0.5)
+    wd = wt.to(dev)
+    wa = ops.absmax(wd)
+    if form == "fwd":
+        x = torch.randn(N, I, 2 * H, 2 * W, generator=gen) * sc
+        b = torch.randn(O, generator=gen) * sc
+        xd = to_nhwc(x, g.IP).to(dev)
+        d = g.fwd_desc(N, 2 * H, 2 * W, precision=fam[0], act_slope=0.01)
+        assert ops.weight_format(d) == 3
+        ops.set_amax(d, ops.absmax(xd), wa)
+        got = from_nhwc(ops.conv_gather(d, xd, ops.pack_weight_fwd(wd, g), bias=b.to(dev)).cpu(), O)
+        ref = F.leaky_relu(F.conv2d(x.double(), wt.double(), b.double(), 2, 1), 0.01)
+    else:
+        gy = torch.randn(N, O, H, W, generator=gen) * sc
+        gd = to_nhwc(gy, g.OP).to(dev)
+        d = g.adj_desc(N, H, W, precision=fam[0])
+        assert ops.weight_format(d) == 3
+        ops.set_amax(d, ops.absmax(gd), wa)
+        got = from_nhwc(ops.conv_gather(d, gd, ops.pack_weight_adj(wd, g)).cpu(), I)
+        ref = F.conv_transpose2d(gy.double(), wt.double(), None, 2, 1)
+    assert relerr(got.double(), ref) <= fam[1]
+    assert L.load().fcd_last_conv_kernel().endswith(b", " + fam[2][:1] + b", true>")
