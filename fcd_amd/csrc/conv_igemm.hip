@@ -105,6 +105,8 @@ struct WgradArgs {
   const float* g_amax;   // FCD_PREC_F16X2 (wgrad3_halo kernel): max |gs|, max |xb| (device scalars)
   const float* x_amax;
   unsigned* ovf;         // FCD_PREC_F16X2: the caller's sticky overflow word (fcd_set_overflow_flag) or NULL
+  int direct;            // conv_wgrad_x3p_kernel without split-K: columns ordered (i / 4, tap, i % 4) and written (or
+                         // accumulated) straight into dw[O][I][KH][KW]; no slab, no wgrad_reduce_kernel
 };
 
 // slabs [splitk][O][KH*KW*IP] -> parameter layout [O][I][KH][KW].  One block per (o, ic input
@@ -1754,7 +1756,12 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3p_kernel(const WgradArgs p, 
   const int b_row = tid / C4B, b_c4 = tid % C4B;
   const int nd = tn * BN + b_c4 * 4;
   const bool b_colok = nd < p.ND;
-  const int tap = nd / p.IP, ci = nd - tap * p.IP;
+  // column nd of the GEMM is (tap, channel) = (nd / IP, nd % IP) -- the slab order -- or, when the result goes straight
+  // into the parameter layout (p.direct), channel group nd / (4 taps'), tap, channel in group: a wave's 64 columns of a
+  // 4 x 4 kernel are then the 16 taps of four channels, 256 contiguous bytes of dw[o]
+  const int ntap = p.KH * p.KW;
+  const int tap = p.direct ? (nd >> 2) % ntap : nd / p.IP;
+  const int ci = p.direct ? ((nd >> 2) / ntap) * 4 : nd - tap * p.IP;
   const int th = tap / p.KW, tw = tap - th * p.KW;
   const int ghw = p.GH * p.GW;
   int b_px[BL], b_n[BL], b_a[BL], b_b[BL];
@@ -1957,6 +1964,33 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3p_kernel(const WgradArgs p, 
   // D[row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)][col = lane&31] of sub-tile (mi, ni)
   float* __restrict__ dst = p.slab + (long)ks * p.O * p.ND;
   const int lr = lane & 31, lh = lane >> 5;
+  if (p.direct) {
+    // no split-K: the tile holds final sums.  Column (i / 4, tap, i % 4) -> dw[o][i][tap]; the same value the slab +
+    // wgrad_reduce_kernel pair would store (0 + v, then dw + v when accumulating): same bits, one pass over dw less
+    float* __restrict__ dw = p.dw;
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni) {
+        const int col = tn * BN + wn * WTN + ni * 32 + lr;
+        const int g4 = col >> 2, i4 = g4 / ntap, tp = g4 - i4 * ntap, i = i4 * 4 + (col & 3);
+        if (col >= p.ND || i >= p.I) continue;
+        const long cbase = (long)i * ntap + tp;
+        float old[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int o = tm * BM + wm * WTM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          old[r] = (p.accumulate && o < p.O) ? dw[(long)o * p.I * ntap + cbase] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int o = tm * BM + wm * WTM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const float v = 0.f + acc[mi][ni][r] * isc;
+          if (o < p.O) dw[(long)o * p.I * ntap + cbase] = p.accumulate ? old[r] + v : v;
+        }
+      }
+    return;
+  }
 #pragma unroll
   for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
@@ -4006,6 +4040,7 @@ extern "C" int fcd_conv_wgrad(const FcdWgradDesc* d, const float* gsmall, const 
   a.ktiles_per_split = fcd_cdiv(a.ktiles, a.splitk);
   a.splitk = fcd_cdiv(a.ktiles, a.ktiles_per_split);
   a.accumulate = d->accumulate;
+  a.direct = 0;
   a.g_amax = a.x_amax = nullptr;
   a.ovf = want_h2 ? fcd_overflow_flag_current() : nullptr;
   {
@@ -4099,6 +4134,9 @@ extern "C" int fcd_conv_wgrad(const FcdWgradDesc* d, const float* gsmall, const 
     a.tiles_m = fcd_cdiv(d->O, bm); a.tiles_n = fcd_cdiv(a.ND, 128);
     dim3 grid(a.tiles_m * a.tiles_n, a.splitk);
     const size_t gsb = (size_t)a.P * a.OP * 4, xbb = (size_t)a.N * a.BH * a.BW * a.IP * 4;
+    // no split-K (the discriminator's 8 M- and 34 M-weight layers: 128 .. 512 pixels against 256 tiles): the kernel
+    // writes the parameter layout itself; the transposing reduction of a 134 MB slab cost more than the GEMM
+    a.direct = (a.splitk == 1 && !getenv("FCD_NO_WGRAD_DIRECT")) ? 1 : 0;
     if (want_h2 && onep) {
       a.g_amax = g_amax; a.x_amax = x_amax;
       note_kernel("conv_wgrad_x3p_kernel<%d, %d, %d, 1>", bm, bm == 64 ? 2 : 4, bm == 64 ? 4 : 2);
@@ -4128,7 +4166,7 @@ extern "C" int fcd_conv_wgrad(const FcdWgradDesc* d, const float* gsmall, const 
     a.tiles_m = fcd_cdiv(d->O, 256); a.tiles_n = fcd_cdiv(a.ND, 128);
     rc = launch_wgrad<256, 128, 4, 2>(a, d->precision, st);
   }
-  if (rc) return rc;
+  if (rc || a.direct) return rc;
   const int ic = wr_ic(d->O, d->I);
   const int blocks = d->O * fcd_cdiv(d->I, ic);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), (size_t)ic * (d->KH * d->KW | 1) * sizeof(float), st, a, ic);

@@ -1074,3 +1074,38 @@ def test_gather_register_staged_f16x2(dev, fam, geom):
         ref = F.conv_transpose2d(gy.double(), wt.double(), None, 2, 1)
     assert relerr(got.double(), ref) <= fam[1]
     assert L.load().fcd_last_conv_kernel().endswith(b", " + fam[2][:1] + b", true>")
+
+
+@pytest.mark.parametrize("fam", [pytest.param((2, 1e-5), id="fp32x3"), pytest.param((3, 1e-6), id="fp32x2")])
+@pytest.mark.parametrize("shape", [(2048, 1024, 4, 2, 1, 8, 4, 4), (1024, 512, 4, 2, 1, 3, 8, 8), (48, 10, 4, 2, 1, 2, 8, 8),
+                                   (300, 36, 3, 1, 1, 2, 9, 7), (72, 20, 4, 2, 1, 5, 6, 10)])
+def test_wgrad_direct_equals_slab_and_reduce(dev, shape, fam, monkeypatch):
+    """conv_wgrad_x3p_kernel without split-K writes (or accumulates into) the parameter layout dw[O][I][KH][KW] itself --
+    columns ordered (channel group, tap, channel) so that a wave stores whole 256-byte runs -- instead of a slab that
+    wgrad_reduce_kernel transposes (FCD_NO_WGRAD_DIRECT=1): same bits, fresh and accumulating, ragged channel counts
+    (10 -> 12 physical input channels) and 3 x 3 kernels included; within the precision's bar of torch in float64."""
+    from fcd_amd import ops
+    O, I, k, s, pd, n, h, w = shape
+    prec, tol = fam
+    g = ops.ConvGeom(O, I, k, s, pd)
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(n, I, h, w, generator=gen)
+    sh, sw = g.small_hw(h, w)
+    gy = torch.randn(n, O, sh, sw, generator=gen)
+    xd, gd = to_nhwc(x, g.IP).to(dev), to_nhwc(gy, g.OP).to(dev)
+
+    def run(accumulate):
+        wd = g.wgrad_desc(n, h, w, precision=prec, accumulate=accumulate)
+        if prec == 3:
+            ops.set_wgrad_amax(wd, ops.absmax(gd), ops.absmax(xd))
+        dw = torch.full((O, I, k, k), 0.25, device=dev) if accumulate else torch.full((O, I, k, k), float("nan"), device=dev)
+        return ops.conv_wgrad(wd, gd, xd, dw=dw)
+
+    monkeypatch.setenv("FCD_NO_WGRAD_DIRECT", "1")
+    old, old_acc = run(False).clone(), run(True).clone()
+    monkeypatch.delenv("FCD_NO_WGRAD_DIRECT")
+    new, new_acc = run(False), run(True)
+    assert torch.equal(old, new) and torch.equal(old_acc, new_acc)
+    ref = torch.nn.grad.conv2d_weight(x.double(), (O, I, k, k), gy.double(), stride=s, padding=pd)
+    assert relerr(new, ref) <= tol
+    assert relerr(new_acc - 0.25, ref) <= 10 * tol
