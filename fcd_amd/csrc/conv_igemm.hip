@@ -2793,9 +2793,19 @@ __device__ __forceinline__ unsigned w3_off(int px, int col) {      // col: chann
   return (unsigned)(px * 128 + (((col >> 4) ^ (((px >> 1) & 1) | (((px >> 3) & 1) << 1))) << 5) + (col & 15) * 2);
 }
 
-template <int NP>   // 3: bf16 x 3 pieces, six MFMAs; 2: FCD_PREC_F16X2, scaled fp16 x 2 pieces, three MFMAs
+// MODE 1 (round 3): the 4 x 4, stride-2, pad-1 layers (the generator's down / up sampling) through the same kernel.  With
+// S[p][q][Y][X] = x[2Y + p - 1][2X + q - 1] (zero outside the image) the layer is a 2 x 2-tap stride-1 convolution over
+// the 4 I "virtual" channels (p, q, c) of S: dW[o][c][2a + p][2b + q] = sum_{y,x} g[y][x][o] S[p][q][y + a][x + b][c].
+// A workgroup's 64 virtual channels are 64 real channels of ONE parity (p, q), so its ring rows are every second input
+// row and every second pixel of it (33 per 32 gradient pixels), fetched straight from x; gradient rows of 64 pixels are
+// walked as two halves ("virtual images" of 32 columns, the left one reading one real pixel of the right as its halo).
+// Four taps instead of nine per staged row pair, but every operand value is still fetched and split once per
+// workgroup instead of once per (tap, 128-channel) column tile of the generic kernel.
+template <int NP, int MODE = 0>   // NP 3: bf16 x 3 pieces, six MFMAs; 2: FCD_PREC_F16X2, scaled fp16 x 2 pieces, three MFMAs
 __global__ __launch_bounds__(64 * W3_WAVES) void wgrad3_halo_x3_kernel(const WgradArgs p, const int ipS, const int ncb,
                                                                              const size_t gs_bytes, const size_t xb_bytes) {
+  constexpr int TKH = MODE ? 2 : 3, TKW = MODE ? 2 : 3, NTAP = TKH * TKW;   // taps of the (virtual) stride-1 convolution
+  constexpr int PADR = MODE ? 0 : 1;                                        // ring row of (virtual) input row yy: yy + PADR
   __shared__ __attribute__((aligned(16))) unsigned char Xp[4 * W3_XSLOT];
   __shared__ __attribute__((aligned(16))) unsigned char Gp[2 * W3_GBUF];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -2805,10 +2815,15 @@ __global__ __launch_bounds__(64 * W3_WAVES) void wgrad3_halo_x3_kernel(const Wgr
   const int bid = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
   const int split = bid / (int)gridDim.x, blk = bid - split * (int)gridDim.x;
   const int cb = blk % ncb, ob = blk / ncb;
-  const int n_begin = split * ipS, n_end = min(p.N, n_begin + ipS);
+  // (MODE 1: "images" are the 32-column halves of the gradient rows, hpi per real image)
+  const int hpi = MODE ? p.GW / 32 : 1;
+  const int n_begin = split * ipS, n_end = min(p.N * hpi, n_begin + ipS);
   const int GH = p.GH;
+  const int r_begin = n_begin / hpi;                      // first real image of this split
+  // MODE 1: parity (py, pq) and the real channel block of this workgroup's 64 virtual channels
+  const int cpb = MODE ? p.IP / 64 : 1, par = MODE ? cb / cpb : 0, py = par >> 1, pq = par & 1, cbr = MODE ? cb - par * cpb : cb;
   // operand windows: from this split's first image on
-  const size_t gs_start = (size_t)n_begin * GH * 32 * p.OP * 4, xb_start = (size_t)n_begin * GH * 32 * p.IP * 4;
+  const size_t gs_start = (size_t)r_begin * GH * p.GW * p.OP * 4, xb_start = (size_t)r_begin * p.BH * p.BW * p.IP * 4;
   __amdgpu_buffer_rsrc_t rgs = __builtin_amdgcn_make_buffer_rsrc((char*)p.gs + gs_start, (short)0,
                                                                  (int)window_bytes(gs_bytes, gs_start), 0x00020000);
   __amdgpu_buffer_rsrc_t rxb = __builtin_amdgcn_make_buffer_rsrc((char*)p.xb + xb_start, (short)0,
@@ -2817,15 +2832,25 @@ __global__ __launch_bounds__(64 * W3_WAVES) void wgrad3_halo_x3_kernel(const Wgr
   // float4 f of an input row = pixel f >> 4 (of 34), channels 64 cb + 4 (f & 15) ..; of a gradient row = pixel f >> 4
   // (of 32), output channels 64 ob + 4 (f & 15) ..   (img: image index relative to n_begin)
   auto load_x = [&](int f, int img, int yy) -> u32x4 {
-    const int px = f >> 4, c4 = f & 15, gx = px - 1;
+    const int px = f >> 4, c4 = f & 15;
+    if constexpr (MODE) {
+      // virtual row yy, virtual pixel 32 half + px of parity (py, pq): real row 2 yy + py - 1, real pixel 2 X + pq - 1
+      const int ri = img / hpi, half = img - ri * hpi;
+      const int ry = 2 * yy + py - 1, rx = 2 * (32 * half + px) + pq - 1;
+      const unsigned okm = 0u - (unsigned)((int)(px < 33) & (int)(ry >= 0) & (int)(ry < p.BH) & (int)(rx >= 0) & (int)(rx < p.BW));
+      const unsigned voff = ((unsigned)(((((ri - r_begin) * p.BH + ry) * p.BW + rx) * p.IP + cbr * 64 + c4 * 4) * 4) & okm) | (OOB & ~okm);
+      return __builtin_amdgcn_raw_buffer_load_b128(rxb, (int)voff, 0, 0);
+    }
+    const int gx = px - 1;
     const unsigned okm = 0u - (unsigned)((int)(px < W3_XW) & (int)(yy >= 0) & (int)(yy < GH) & (int)(gx >= 0) & (int)(gx < 32));
-    const unsigned voff = ((unsigned)((((img * GH + yy) * 32 + gx) * p.IP + cb * 64 + c4 * 4) * 4) & okm) | (OOB & ~okm);
+    const unsigned voff = ((unsigned)(((((img - r_begin) * GH + yy) * 32 + gx) * p.IP + cb * 64 + c4 * 4) * 4) & okm) | (OOB & ~okm);
     return __builtin_amdgcn_raw_buffer_load_b128(rxb, (int)voff, 0, 0);
   };
   auto load_g = [&](int f, int img, int y) -> u32x4 {
     const int px = f >> 4, c = ob * 64 + 4 * (f & 15);
+    const int ri = img / hpi, half = img - ri * hpi;
     const unsigned okm = 0u - (unsigned)((int)(y < GH) & (int)(c < p.OP));
-    const unsigned voff = ((unsigned)((((img * GH + y) * 32 + px) * p.OP + c) * 4) & okm) | (OOB & ~okm);
+    const unsigned voff = ((unsigned)(((((ri - r_begin) * GH + y) * p.GW + 32 * half + px) * p.OP + c) * 4) & okm) | (OOB & ~okm);
     return __builtin_amdgcn_raw_buffer_load_b128(rgs, (int)voff, 0, 0);
   };
   float sg = 1.f, sx = 1.f;
@@ -2856,9 +2881,9 @@ __global__ __launch_bounds__(64 * W3_WAVES) void wgrad3_halo_x3_kernel(const Wgr
     *reinterpret_cast<uint2*>(dst + plane_bytes) = make_uint2(m0, m1);
     *reinterpret_cast<uint2*>(dst + 2 * plane_bytes) = make_uint2(cvt_pk_bf16(s0, s1), cvt_pk_bf16(s2, s3));
   };
-  // input row yy lives in ring slot (yy + 1) & 3
+  // (virtual) input row yy lives in ring slot (yy + PADR) & 3
   auto store_x = [&](const u32x4 v, int f, int yy) {
-    if (f < W3_XW * 16) split_store(v, Xp + ((yy + 1) & 3) * W3_XSLOT + w3_off(f >> 4, 4 * (f & 15)), W3_XPLANE, sx);
+    if (f < W3_XW * 16) split_store(v, Xp + ((yy + PADR) & 3) * W3_XSLOT + w3_off(f >> 4, 4 * (f & 15)), W3_XPLANE, sx);
   };
   auto store_g = [&](const u32x4 v, int f, int y) { split_store(v, Gp + (y & 1) * W3_GBUF + w3_off(f >> 4, 4 * (f & 15)), W3_GPLANE, sg); };
 
@@ -2872,11 +2897,11 @@ __global__ __launch_bounds__(64 * W3_WAVES) void wgrad3_halo_x3_kernel(const Wgr
     const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf16x8_t, v);
   };
-  f32x4 acc[2][9], acc2[2][9];
+  f32x4 acc[2][NTAP], acc2[2][NTAP];
 #pragma unroll
   for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
-    for (int t = 0; t < 9; ++t) acc[ot][t] = acc2[ot][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NTAP; ++t) acc[ot][t] = acc2[ot][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // the 544 + 512 float4 of (input row, gradient row) are dealt to the 512 threads: input item tid, gradient item tid,
   // and the last 32 input items to the first 32 threads (each load keeps one buffer descriptor)
@@ -2893,18 +2918,18 @@ __global__ __launch_bounds__(64 * W3_WAVES) void wgrad3_halo_x3_kernel(const Wgr
     if (wave == 0 && lane < NX4 - 512) store_x(st[2], 512 + lane, yx);
   };
   for (int n = n_begin; n < n_end; ++n) {
-    const int img = n - n_begin;
-    // prologue of an image: input rows -1 (zeros), 0, 1 and gradient row 0; every wave is past the last step of the
-    // previous image (its closing barrier)
-    load_items(img, -1, 0);
-    store_items(-1, 0, true);
-    load_items(img, 0, 1);
-    store_items(0, 1, true);
-    load_items(img, 1, GH);
-    store_items(1, 0, false);
-    load_items(img, 2, GH);
-    store_items(2, 0, false);
-    load_items(img, 3, 2);             // staged: input row 3, gradient row 2
+    const int img = n;
+    // prologue of an image: ring rows 0 .. 3 (MODE 0: input rows -1 (zeros), 0, 1, 2) and gradient rows 0, 1; every wave
+    // is past the last step of the previous image (its closing barrier)
+    load_items(img, 0 - PADR, 0);
+    store_items(0 - PADR, 0, true);
+    load_items(img, 1 - PADR, 1);
+    store_items(1 - PADR, 1, true);
+    load_items(img, 2 - PADR, GH);
+    store_items(2 - PADR, 0, false);
+    load_items(img, 3 - PADR, GH);
+    store_items(3 - PADR, 0, false);
+    load_items(img, 4 - PADR, 2);      // staged: ring row 4, gradient row 2
     __syncthreads();
     for (int y = 0; y < GH; ++y) {
       const unsigned char* Grow = Gp + (y & 1) * W3_GBUF;
@@ -2920,22 +2945,22 @@ __global__ __launch_bounds__(64 * W3_WAVES) void wgrad3_halo_x3_kernel(const Wgr
       // one tap ahead: the fragments of tap t+1 are in flight under the MFMAs of tap t
       bf16x8_t xh[2], xm[2], xl[2];
       auto load_tap = [&](int t, int b) {
-        const unsigned char* Xrow = Xp + ((y + t / 3) & 3) * W3_XSLOT;      // input row y + th - 1
-        xh[b] = frag(Xrow, px + t % 3, xcol);
-        if constexpr (NP == 3) xm[b] = frag(Xrow + W3_XPLANE, px + t % 3, xcol);
-        xl[b] = frag(Xrow + (NP - 1) * W3_XPLANE, px + t % 3, xcol);
+        const unsigned char* Xrow = Xp + ((y + t / TKW) & 3) * W3_XSLOT;      // ring row y + th (MODE 0: input row y + th - 1)
+        xh[b] = frag(Xrow, px + t % TKW, xcol);
+        if constexpr (NP == 3) xm[b] = frag(Xrow + W3_XPLANE, px + t % TKW, xcol);
+        xl[b] = frag(Xrow + (NP - 1) * W3_XPLANE, px + t % TKW, xcol);
       };
       load_tap(0, 0);
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        if (t + 1 < 9) load_tap(t + 1, (t + 1) & 1);
-        if (t == 3) {
-          // Every wave has read input row y-1 (taps 0 .. 2) and the gradient row: their places take the staged input
-          // row y+3 and gradient row y+2, which the NEXT step's barrier publishes for step y+2.  The barrier sits in
+      for (int t = 0; t < NTAP; ++t) {
+        if (t + 1 < NTAP) load_tap(t + 1, (t + 1) & 1);
+        if (t == TKW) {
+          // Every wave has read ring row y (the first tap row) and the gradient row: their places take the staged ring
+          // row y+4 and gradient row y+2, which the NEXT step's barrier publishes for step y+2.  The barrier sits in
           // the middle of the step, with the next tap's fragments already loaded, so no wave restarts cold after it.
           __syncthreads();
-          store_items(y + 3, y + 2, true);
-          load_items(img, y + 4, y + 3);
+          store_items(y + 4 - PADR, y + 2, true);
+          load_items(img, y + 5 - PADR, y + 3);
         }
         if constexpr (NP <= 2) {
 #pragma unroll
@@ -2970,8 +2995,10 @@ __global__ __launch_bounds__(64 * W3_WAVES) void wgrad3_halo_x3_kernel(const Wgr
 #pragma unroll
   for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int col = t * p.IP + cb * 64 + cq * 16 + c16;
+    for (int t = 0; t < NTAP; ++t) {
+      // MODE 1: virtual tap (a, b) = (t / 2, t % 2) of parity (py, pq) is tap (2a + py, 2b + pq) of the 4 x 4 kernel
+      const int col = MODE ? ((2 * (t / TKW) + py) * 4 + 2 * (t % TKW) + pq) * p.IP + cbr * 64 + cq * 16 + c16
+                           : t * p.IP + cb * 64 + cq * 16 + c16;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int o = ob * 64 + 16 * (2 * oh + ot) + 4 * kq + e;
@@ -3948,18 +3975,33 @@ static int halo12w_plan(const FcdWgradDesc* d, int* rows, int* R, int* nch, int*
 
 // The halo form of the 3x3 weight gradient on 32-pixel-wide images under FCD_PREC_BF16X3 (wgrad3_halo_x3_kernel):
 // number of slabs (= splits over whole images), or 0; *ipS = images per split.
-static int halo3w_plan(const FcdWgradDesc* d, int* ipS) {
+static int halo3w_plan(const FcdWgradDesc* d, int* ipS, int* mode = nullptr) {
   if (d->splitk > 0 || (d->precision != FCD_PREC_BF16X3 && d->precision != FCD_PREC_F16X2 && d->precision != FCD_PREC_F16) ||
       getenv("FCD_NO_WGRAD3"))
     return 0;
-  if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->GW != 32 || d->BW != 32 || d->BH != d->GH) return 0;
   if (d->IP % 64 != 0 || d->OP % 64 != 0 || d->O <= 32 || d->GH < 2) return 0;
-  const long blocks = (long)(d->OP / 64) * (d->IP / 64);
-  if (blocks * d->N < 192) return 0;                       // too few workgroups: the split-K kernel fills the chip better
-  long per = ((long)d->N * blocks + 128) / 256;            // images per split: about one workgroup per CU
+  long blocks, images;
+  if (d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->GW == 32 && d->BW == 32 && d->BH == d->GH) {
+    blocks = (long)(d->OP / 64) * (d->IP / 64);
+    images = d->N;
+    if (mode) *mode = 0;
+  } else if (d->KH == 4 && d->KW == 4 && d->stride == 2 && d->pad == 1 && (d->GW == 32 || d->GW == 64) && d->BW == 2 * d->GW &&
+             d->BH == 2 * d->GH && !getenv("FCD_NO_WGRAD4")) {
+    // MODE 1 of the kernel: 2 x 2 taps over the four parities of the input, 32-column halves of the gradient rows
+    blocks = (long)(d->OP / 64) * (4 * d->IP / 64);
+    images = (long)d->N * (d->GW / 32);
+    if (mode) *mode = 1;
+  } else {
+    return 0;
+  }
+  if (blocks * images < 192) return 0;                     // too few workgroups: the split-K kernel fills the chip better
+  long per = (images * blocks + 128) / 256;                // (virtual) images per split: about one workgroup per CU
   if (per < 1) per = 1;
+  // 32-bit lane offsets inside a split's window of real images
+  const long real = per / (d->GW / 32 > 0 ? d->GW / 32 : 1) + 2;
+  if ((size_t)real * d->BH * d->BW * d->IP * 4 >= (1ull << 31) || (size_t)real * d->GH * d->GW * d->OP * 4 >= (1ull << 31)) return 0;
   *ipS = (int)per;
-  return fcd_cdiv(d->N, (int)per);
+  return fcd_cdiv(images, (int)per);
 }
 
 static int wgrad_bm(const FcdWgradDesc* d) { return d->O <= 32 ? 32 : (d->O <= 64 ? 64 : (d->O <= 128 ? 128 : 256)); }
@@ -4078,25 +4120,24 @@ extern "C" int fcd_conv_wgrad(const FcdWgradDesc* d, const float* gsmall, const 
                          (size_t)a.P * a.OP * 4, (size_t)a.N * a.BH * a.BW * a.IP * 4);
     }
     rc = fcd_check_launch("conv_wgrad");
-  } else if (int ipS = 0, slabs3 = halo3w_plan(d, &ipS); slabs3) {
+  } else if (int ipS = 0, mode3 = 0, slabs3 = halo3w_plan(d, &ipS, &mode3); slabs3) {
     a.splitk = slabs3;
-    const int ncb = d->IP / 64;
+    const int ncb = (mode3 ? 4 : 1) * d->IP / 64;
     dim3 grid((d->OP / 64) * ncb, slabs3);
-    if (want_h2 && onep) {
-      a.g_amax = g_amax; a.x_amax = x_amax;
-      note_kernel("wgrad3_halo_x3_kernel<1>");
-      hipLaunchKernelGGL(wgrad3_halo_x3_kernel<1>, grid, dim3(64 * W3_WAVES), 0, st, a, ipS, ncb,
-                         (size_t)a.P * a.OP * 4, (size_t)a.N * a.BH * a.BW * a.IP * 4);
-    } else if (want_h2) {
-      a.g_amax = g_amax; a.x_amax = x_amax;
-      note_kernel("wgrad3_halo_x3_kernel<2>");
-      hipLaunchKernelGGL(wgrad3_halo_x3_kernel<2>, grid, dim3(64 * W3_WAVES), 0, st, a, ipS, ncb,
-                         (size_t)a.P * a.OP * 4, (size_t)a.N * a.BH * a.BW * a.IP * 4);
-    } else {
-      note_kernel("wgrad3_halo_x3_kernel");
-      hipLaunchKernelGGL(wgrad3_halo_x3_kernel<3>, grid, dim3(64 * W3_WAVES), 0, st, a, ipS, ncb,
-                         (size_t)a.P * a.OP * 4, (size_t)a.N * a.BH * a.BW * a.IP * 4);
-    }
+    const size_t gsb = (size_t)a.P * a.OP * 4, xbb = (size_t)a.N * a.BH * a.BW * a.IP * 4;
+    const int np = want_h2 ? (onep ? 1 : 2) : 3;
+    if (want_h2) { a.g_amax = g_amax; a.x_amax = x_amax; }
+    if (np == 3) note_kernel(mode3 ? "wgrad3_halo_x3_kernel<3, 1>" : "wgrad3_halo_x3_kernel");
+    else note_kernel(mode3 ? "wgrad3_halo_x3_kernel<%d, 1>" : "wgrad3_halo_x3_kernel<%d>", np);
+#define FCD_LAUNCH_W3(NP_)                                                                                                  \
+  do {                                                                                                                     \
+    if (mode3) hipLaunchKernelGGL((wgrad3_halo_x3_kernel<NP_, 1>), grid, dim3(64 * W3_WAVES), 0, st, a, ipS, ncb, gsb, xbb); \
+    else hipLaunchKernelGGL((wgrad3_halo_x3_kernel<NP_, 0>), grid, dim3(64 * W3_WAVES), 0, st, a, ipS, ncb, gsb, xbb);       \
+  } while (0)
+    if (np == 1) FCD_LAUNCH_W3(1);
+    else if (np == 2) FCD_LAUNCH_W3(2);
+    else FCD_LAUNCH_W3(3);
+#undef FCD_LAUNCH_W3
     rc = fcd_check_launch("conv_wgrad");
   } else if (int hv = 0, slabs12 = halo12w_plan(d, &h_rows, &h_R, &h_nch, &hv); slabs12) {
     a.splitk = slabs12;

@@ -1109,3 +1109,45 @@ def test_wgrad_direct_equals_slab_and_reduce(dev, shape, fam, monkeypatch):
     ref = torch.nn.grad.conv2d_weight(x.double(), (O, I, k, k), gy.double(), stride=s, padding=pd)
     assert relerr(new, ref) <= tol
     assert relerr(new_acc - 0.25, ref) <= 10 * tol
+
+
+# (O, I, n, small h, small w): 4x4 stride-2 layers whose weight gradient takes the halo kernel's MODE 1
+W4_SHAPES = [(256, 128, 32, 32, 32),      # the generator's 128 -> 256 down-sampling / 256 -> 128 up-sampling layer
+             (128, 64, 16, 64, 64),       # 64-pixel gradient rows: two 32-column halves per row
+             (192, 64, 17, 32, 32),       # 192 output channels, an odd number of images (ragged last split)
+             (128, 128, 12, 20, 32),      # 20 rows
+             (128, 64, 13, 24, 64)]       # halves + odd image count + 24 rows
+
+
+@pytest.mark.parametrize("fam", [pytest.param((2, 1e-5, b"<3, 1>"), id="fp32x3"), pytest.param((3, 1e-6, b"<2, 1>"), id="fp32x2"),
+                                 pytest.param((4, 1e-3, b"<1, 1>"), id="fp16")])
+@pytest.mark.parametrize("shape", W4_SHAPES)
+def test_wgrad4_halo(dev, shape, fam, monkeypatch):
+    """Weight gradient of the 4x4 stride-2 layers through the halo kernel (wgrad3_halo_x3_kernel<NP, 1>: 2 x 2 taps over the
+    four input parities, every operand row fetched and split once per workgroup): against torch in float64, fresh and
+    accumulating, and against the generic split-once kernel (FCD_NO_WGRAD4=1) to the same bar."""
+    from fcd_amd import _lib as L, ops
+    O, I, n, h, w = shape
+    prec, tol, tag = fam
+    g = ops.ConvGeom(O, I, 4, 2, 1)
+    gen = torch.Generator().manual_seed(41)
+    big = torch.randn(n, I, 2 * h, 2 * w, generator=gen)
+    small = torch.randn(n, O, h, w, generator=gen) * 0.01
+    bd, sd = to_nhwc(big, g.IP).to(dev), to_nhwc(small, g.OP).to(dev)
+
+    def desc(acc=False):
+        d = g.wgrad_desc(n, 2 * h, 2 * w, precision=prec, accumulate=acc)
+        return ops.set_wgrad_amax(d, ops.absmax(sd), ops.absmax(bd)) if prec >= 3 else d
+
+    dw = ops.conv_wgrad(desc(), sd, bd)
+    assert L.load().fcd_last_conv_kernel() == b"wgrad3_halo_x3_kernel" + tag
+    ref = torch.nn.grad.conv2d_weight(big.double(), (O, I, 4, 4), small.double(), stride=2, padding=1)
+    assert relerr(dw.cpu(), ref) <= tol
+    base = float(ref.abs().max()) * 0.5
+    acc = torch.full_like(dw, base)
+    ops.conv_wgrad(desc(True), sd, bd, dw=acc)
+    assert relerr(acc.cpu() - base, ref) <= 10 * tol
+    monkeypatch.setenv("FCD_NO_WGRAD4", "1")
+    old = ops.conv_wgrad(desc(), sd, bd)
+    assert L.load().fcd_last_conv_kernel().startswith(b"conv_wgrad_x3p_kernel")
+    assert relerr(old.cpu(), ref) <= tol and relerr(dw, old) <= 2 * tol
