@@ -374,10 +374,17 @@ constexpr int ah_maxpx(int bm) { return bm == 256 ? 396 : 264; }   // (4 + 2) x 
 // tile with 2 x 4 waves), which is what bounds the discriminator's deep layers (few output rows, K = 4096 .. 16384).
 // Same pieces, same products in the same order per accumulator: bit-identical to that form.  With both maxima
 // attached (FCD_PREC_F16X2 / _F16, weight format 3) the pieces are two / one scaled fp16 ones.
+// PP ("phase pair", A-halo form of the 2 x 2-tap phases of a stride-2 adjoint with at most 64 output channels): a workgroup
+// computes the two phases (py, 0) and (py, 1) of its 256 grid pixels side by side -- wave column wn IS the phase's px.
+// Both phases read the same halo planes (the union region, one pixel wider: pad_w 1 and 0), each wave with its own
+// pixel shift, and their weights sit next to each other in the B stage (rows 0 .. 63 / 64 .. 127).  That turns the
+// 256 x 64 tile (8 x 1 waves of 32 x 64: one fragment read per MFMA, LDS-read-bound) into the 256 x 128 tile's
+// 4 x 2 waves of 64 x 64 (two reads per three MFMAs).  blockIdx.y = py.
 template <int BM, int BN, int WM, int WN, int S, int PREC, bool N16 = false, bool BPRE = false, bool AH = false, int NP = 3,
-          bool RS = false>
+          bool RS = false, bool PP = false>
 __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const GatherArgs p, const size_t in_bytes,
                                                                        const unsigned w_bytes) {
+  static_assert(!PP || (AH && BPRE && BM == 256 && BN == 128 && WM == 4 && WN == 2 && S == 3), "PP shape");
   static_assert(!N16 || (BN == 32 && WN == 1 && PREC == FCD_PREC_F32), "N16 shape");
   constexpr int BNC = N16 ? 16 : BN;            // output channels this block computes
   constexpr int NW = WM * WN, NT = 64 * NW;     // 4 waves (one per SIMD) or 8 (two per SIMD)
@@ -398,28 +405,32 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
   constexpr int AH_MAXPX = ah_maxpx(BM);
   constexpr int AH_F4 = AH ? 3 * AH_MAXPX * 4 : 0;                 // three planes of 64 bytes per halo pixel
 
-  __shared__ float4 smem[S * STAGE + BM / 2 + AH_F4];   // ring + rowoff (BM longs) (+ the halo planes)
+  constexpr int ROW_F4 = PP ? BM : BM / 2;              // rowoff: BM longs (PP: one table per phase of the pair)
+  __shared__ float4 smem[S * STAGE + ROW_F4 + AH_F4];   // ring + rowoff (+ the halo planes)
   long* rowoff = reinterpret_cast<long*>(smem + S * STAGE);
-  unsigned char* const Apl = reinterpret_cast<unsigned char*>(smem + S * STAGE + BM / 2);
+  unsigned char* const Apl = reinterpret_cast<unsigned char*>(smem + S * STAGE + ROW_F4);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int tn = bid % p.tiles_n, tm = bid / p.tiles_n;
-  const int phase = blockIdx.y / p.splitk, ks = blockIdx.y % p.splitk;
-  const int pad_h = p.pad_h[phase], pad_w = p.pad_w[phase];
+  // PP: phase0 = (py, 0) is the block's, phase = (py, wn) the wave's; the halo region is the union of both (pad_w = 1)
+  const int phase0 = PP ? 2 * (int)blockIdx.y : (int)blockIdx.y / p.splitk, ks = PP ? 0 : blockIdx.y % p.splitk;
+  const int phase = PP ? phase0 + wn : phase0;
+  const int pad_h = p.pad_h[phase0], pad_w = PP ? 1 : p.pad_w[phase0];
   const int ghw = p.GH * p.GW;
 
-  for (int r = tid; r < BM; r += NT) {
-    const int m = tm * BM + r;
+  for (int r = tid; r < (PP ? 2 * BM : BM); r += NT) {
+    const int ph = PP ? phase0 + r / BM : phase0;
+    const int m = tm * BM + (PP ? r % BM : r);
     long off = -1;
     if (m < p.M) {
       const int n = m / ghw, rem = m - n * ghw;
       const int a = rem / p.GW, b = rem - a * p.GW;
       off = p.splitk > 1 ? (long)m * p.CoutP
-                         : (((long)n * p.OH + a * p.ostride + p.ooff_h[phase]) * p.OW + b * p.ostride +
-                            p.ooff_w[phase]) * p.CoutP;
+                         : (((long)n * p.OH + a * p.ostride + p.ooff_h[ph]) * p.OW + b * p.ostride +
+                            p.ooff_w[ph]) * p.CoutP;
     }
     rowoff[r] = off;
   }
@@ -428,7 +439,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
   const int n0 = __builtin_amdgcn_readfirstlane(min(tm * BM, p.M - 1) / ghw);
   const size_t in_start = (size_t)n0 * p.IH * p.IW * p.Cin * 4;
   const i32x4 rin = make_rsrc(reinterpret_cast<const char*>(p.in) + in_start, window_bytes(in_bytes, in_start));
-  const i32x4 rw = make_rsrc(p.w + (long)phase * p.w_phase_stride, w_bytes);
+  const i32x4 rw = make_rsrc(p.w + (long)phase0 * p.w_phase_stride, w_bytes);      // (PP: w_bytes spans the two phases)
   const unsigned lds0 = lds_addr_of(smem);
 
   // this lane fills slot (lane&7) of row rl = 8*wave + (lane>>3) (+RPI per instruction); the slot
@@ -458,8 +469,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
 #pragma unroll
     for (int i = 0; i < BL; ++i) {
       const int ii = wave + NW * i, plane = ii / (BN / 16), row = 16 * (ii % (BN / 16)) + (lane >> 2);
-      const int co = tn * BN + row, chunk = (lane & 3) ^ ((row >> 2) & 3);
-      b_base[i] = (co < p.Cout && ii < BUNITS) ? (unsigned)((((long)plane * p.Cout + co) * p.K + chunk * 8) * 2) : OOB;
+      // (PP: stage rows 0 .. 63 hold phase (py, 0)'s output channels, rows 64 .. 127 phase (py, 1)'s)
+      const int co = PP ? (row & 63) : tn * BN + row, chunk = (lane & 3) ^ ((row >> 2) & 3);
+      const long phoff = PP ? (long)(row >> 6) * p.w_phase_stride * 4 : 0;
+      b_base[i] = (co < p.Cout && ii < BUNITS) ? (unsigned)((((long)plane * p.Cout + co) * p.K + chunk * 8) * 2 + phoff) : OOB;
     }
   } else {
 #pragma unroll
@@ -756,7 +769,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
     // ---- AH: halo geometry, the staged next slice, the planes
     // (KH x KW taps at stride 1 on a GW-wide grid, 3 x 3 with pad 1 or the 2 x 2 taps of one phase of a 4 x 4 stride-2
     //  adjoint with pad 0 / 1: the halo region has KH - 1 extra rows and KW - 1 extra columns)
-    const int W2 = p.GW + p.KW - 1, APX = (BM / p.GW + p.KH - 1) * W2, PB = APX * 64;   // halo row pitch, halo pixels, plane bytes
+    // (PP: the union of the pair's regions, pad_w = 1 and 0: one more column)
+    const int W2 = p.GW + p.KW - 1 + (PP ? 1 : 0), APX = (BM / p.GW + p.KH - 1) * W2, PB = APX * 64;   // halo row pitch, halo pixels, plane bytes
     const int ah_y0 = (tm * BM - n0 * ghw) / p.GW;                          // first output row of this tile in its image
     int hbase[TM];                                                          // halo pixel of this lane's rows at tap (0, 0)
     constexpr int NLH = (AH_MAXPX * 8 + NT - 1) / NT;                       // float4 of a slice per thread (7)
@@ -767,7 +781,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
 #pragma unroll
       for (int mi = 0; mi < TM; ++mi) {
         const int r = wm * WTM + mi * 32 + lr;
-        hbase[mi] = (r / p.GW) * W2 + r % p.GW;
+        hbase[mi] = (r / p.GW) * W2 + r % p.GW + (PP ? 1 - p.pad_w[phase] : 0);       // PP: this wave's phase starts pad_w[phase] left of the pixel
       }
     }
     // float4 f of a slice = halo pixel f >> 3, channels 4 (f & 7) .. of the slice
@@ -1283,12 +1297,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
   for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni) {
-      const int co = tn * BN + wn * WTN + ni * 32 + lr;
+      const int co = PP ? ni * 32 + lr : tn * BN + wn * WTN + ni * 32 + lr;      // PP: the wave's 64 columns are its phase's channels
       if (co >= p.CoutP) continue;
       const bool cok = co < p.Cout;
       long off[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) off[r] = rowoff[wm * WTM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
+      for (int r = 0; r < 16; ++r) off[r] = rowoff[(PP ? wn * BM : 0) + wm * WTM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
       float v[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) v[r] = acc[mi][ni][r];
@@ -1348,7 +1362,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
         double q2 = (double)qsum[ni] + 2.0 * shd * (double)ssum[ni] + cn * shd * shd;
         s2 += __shfl_xor(s2, 32);
         q2 += __shfl_xor(q2, 32);
-        const int co = tn * BN + wn * WTN + ni * 32 + lr;
+        const int co = PP ? ni * 32 + lr : tn * BN + wn * WTN + ni * 32 + lr;
         if (lh == 0 && co < p.CoutP) {
           double* d2 = p.stats + (chunk * p.CoutP + co) * 2;
           d2[0] = s2;
@@ -3559,6 +3573,23 @@ bool gather_ahalo(const FcdConvDesc* d, int rows) {
   return d->GH % (rows / d->GW) == 0;
 }
 
+// The phase-pair form (template flag PP) of the A-halo kernel: the four 2 x 2-tap phases of a stride-2 adjoint with at
+// most 64 output channels, two phases (py, 0) / (py, 1) per workgroup on the 256 x 128 tile's wave layout.  Taken when
+// the 256 x 64 A-halo launch would be and the halved grid still covers the chip.  FCD_NO_PP=1: A/B runs.
+bool gather_pp(const FcdConvDesc* d) {
+  if (getenv("FCD_NO_PP")) return false;
+  if (!gather_big_tile(d)) return false;
+  int bm, bn;
+  gather_tile(d, bm, bn);
+  if (bn != 64 || d->nphase != 4 || d->KH != 2 || d->KW != 2 || !gather_ahalo(d, 256)) return false;
+  for (int py = 0; py < 2; ++py) {
+    if (d->pad_w[2 * py] != 1 || d->pad_w[2 * py + 1] != 0 || d->pad_h[2 * py] != d->pad_h[2 * py + 1]) return false;
+    if (d->ooff_h[2 * py] != d->ooff_h[2 * py + 1]) return false;
+  }
+  const long M = (long)d->N * d->GH * d->GW;
+  return (long)fcd_cdiv(M, 256) * 2 >= 256;
+}
+
 // The halo form of the 7x7, 64 -> <= 16 channel convolution (conv7_halo_kernel): rows per workgroup, or 0.
 int halo7_fwd_rows(const FcdConvDesc* d, const GatherArgs& a) {
   if (d->precision == FCD_PREC_BF16 || d->KH != 7 || d->KW != 7 || d->nphase != 1 || d->istride != 1 || d->ostride != 1) return 0;
@@ -3671,6 +3702,16 @@ int run_gather(const FcdConvDesc* d, GatherArgs& a, hipStream_t st) {
       grid = dim3(a.tiles_m * a.tiles_n, a.nphase * a.splitk);
       if (bn == 128 && gather_ahalo(d, 256)) FCD_LAUNCH_PRESPLIT(256, 128, 4, 2, 3, true);
       else if (bn == 128) FCD_LAUNCH_PRESPLIT(256, 128, 4, 2, 2, false);
+      else if (h2 && gather_pp(d)) {     // (the three-plane instance spills on this tile: scaled-fp16 forms only)
+        // two phases per workgroup: the 256 x 128 tile's 4 x 2 waves of 64 x 64, wave column = phase column
+        a.tiles_n = 1;
+        grid = dim3(a.tiles_m, 2);
+        const unsigned w2 = 2 * w_bytes;
+        const int np = a.onep ? 1 : 2;
+        note_kernel("conv_gather_dma_kernel<256, 128 (phase pairs), 4, 2, 3, 2, false, true, true, %d>", np);
+        if (np == 1) hipLaunchKernelGGL((conv_gather_dma_kernel<256, 128, 4, 2, 3, X3, false, true, true, 1, false, true>), grid, dim3(512), 0, st, a, in_bytes, w2);
+        else hipLaunchKernelGGL((conv_gather_dma_kernel<256, 128, 4, 2, 3, X3, false, true, true, 2, false, true>), grid, dim3(512), 0, st, a, in_bytes, w2);
+      }
       else if (gather_ahalo(d, 256)) FCD_LAUNCH_PRESPLIT(256, 64, 8, 1, 3, true);
       else FCD_LAUNCH_PRESPLIT(256, 64, 8, 1, 3, false);
     } else if (bn == 128 && gather_ahalo(d, 128)) {
@@ -3746,14 +3787,14 @@ int run_gather(const FcdConvDesc* d, GatherArgs& a, hipStream_t st) {
 }
 
 // chunks per image when the statistics can ride in the epilogue, else 0
-int fused_stats_chunks(const FcdConvDesc* d) {
+int fused_stats_chunks(const FcdConvDesc* d, bool h2) {
   int bm, bn;
   int hchunks = 0;
   if (halo12_rows(d, &hchunks)) return hchunks;      // the halo kernel's sum pass carries the statistics
   gather_tile(d, bm, bn);
   if (bn == 16 || resolve_splitk(d) != 1) return 0;
   // rows per wave: the pre-split kernels run 4 x 2 waves on 128 rows, 4 x 2 or 8 x 1 on 256
-  const int wtm = (gather_big_tile(d) && bn == 128) ? 64 : wants_split_weights(d) ? 32 : gather_rs(d, bm, bn) ? 32 : gather_wave_rows(bm, bn);
+  const int wtm = ((gather_big_tile(d) && bn == 128) || (h2 && gather_pp(d))) ? 64 : wants_split_weights(d) ? 32 : gather_rs(d, bm, bn) ? 32 : gather_wave_rows(bm, bn);
   const long ghw = (long)d->GH * d->GW;
   if (ghw % wtm) return 0;
   return (int)(d->nphase * (ghw / wtm));
@@ -3840,7 +3881,7 @@ extern "C" size_t fcd_conv_gather_stats_workspace_bytes(const FcdConvDesc* d) {
   const NormDesc nd = normalise(d);
   d = &nd.d;
   const long hw = (long)d->OH * d->OW;
-  const int chunks = fused_stats_chunks(d);
+  const int chunks = fused_stats_chunks(d, nd.h2);
   size_t stats = fcd_instnorm_workspace_bytes(d->N, (int)hw, d->CoutP);
   if (chunks > 0) stats = std::max(stats, (size_t)d->N * chunks * d->CoutP * 2 * sizeof(double));
   const size_t conv = (fcd_conv_workspace_bytes(d) + 255) / 256 * 256;
@@ -3890,7 +3931,7 @@ int conv_stats_impl(const FcdConvDesc* d, const float* in, const float* w_packed
   a.a_amax = a_amax; a.w_amax = w_amax;
   a.onep = nd.onep ? 1 : 0;
   a.ovf = a_amax ? fcd_overflow_flag_current() : nullptr;
-  const int chunks = fused_stats_chunks(d);
+  const int chunks = fused_stats_chunks(d, nd.h2);
   const long hw = (long)d->OH * d->OW;
   if (chunks == 0) {   // shape does not allow the fused form: convolution, then the two-pass statistics
     rc = run_gather(d, a, st);

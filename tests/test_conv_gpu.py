@@ -1151,3 +1151,52 @@ def test_wgrad4_halo(dev, shape, fam, monkeypatch):
     old = ops.conv_wgrad(desc(), sd, bd)
     assert L.load().fcd_last_conv_kernel().startswith(b"conv_wgrad_x3p_kernel")
     assert relerr(old.cpu(), ref) <= tol and relerr(dw, old) <= 2 * tol
+
+
+@pytest.mark.parametrize("fam", [pytest.param((3, 1e-6), id="fp32x2"), pytest.param((4, 1e-3), id="fp16")])
+@pytest.mark.parametrize("geom", [(128, 64, 32, 64, 64), (128, 64, 33, 32, 32), (96, 40, 9, 64, 64), (128, 64, 36, 32, 64)])
+def test_gather_phase_pairs_equal_single_phases(dev, geom, fam, monkeypatch):
+    """The four 2 x 2-tap phases of a stride-2 adjoint with at most 64 output channels, two phases per workgroup on the
+    256 x 128 tile's wave layout (template flag PP, scaled-fp16 precisions): same bits as one phase per workgroup on
+    256 x 64 tiles (FCD_NO_PP=1) with the epilogue operands; the fused InstanceNorm statistics (per-wave sums over 64
+    instead of 32 rows) to rounding; within the precision's bar of torch in float64."""
+    from fcd_amd import _lib as L, ops
+    O, I, N, H, W = geom
+    prec, tol = fam
+    g = ops.ConvGeom(O, I, 4, 2, 1)
+    gen = torch.Generator().manual_seed(57)
+    wt = torch.randn(O, I, 4, 4, generator=gen) / (4 * I ** 0.5)
+    wd = wt.to(dev)
+    gy = torch.randn(N, O, H, W, generator=gen)
+    mask = torch.randn(N, I, 2 * H, 2 * W, generator=gen)
+    res = torch.randn(N, I, 2 * H, 2 * W, generator=gen)
+    gd, md, rd = to_nhwc(gy, g.OP).to(dev), to_nhwc(mask, g.IP).to(dev), to_nhwc(res, g.IP).to(dev)
+    wa, ga = ops.absmax(wd), ops.absmax(gd)
+
+    def run():
+        d = g.adj_desc(N, H, W, precision=prec, mask_slope=0.2)
+        fmt = ops.weight_format(d)
+        if fmt == 2:
+            ops.set_amax(d, ga, wa)
+        wp = ops.pack_weight_adj_h2(wd, g, wa) if fmt == 2 else ops.pack_weight_adj_x3(wd, g)
+        out = ops.conv_gather(d, gd, wp, mask=md, residual=rd)
+        k1 = L.load().fcd_last_conv_kernel()
+        d2 = g.adj_desc(N, H, W, precision=prec)
+        if fmt == 2:
+            ops.set_amax(d2, ga, wa)
+        z, mean, rstd, varu = ops.conv_gather_stats(d2, gd, wp, want_var=True)
+        return out, z, mean, rstd, varu, k1
+
+    new = run()
+    assert b"(phase pairs)" in new[5], new[5]
+    monkeypatch.setenv("FCD_NO_PP", "1")
+    old = run()
+    assert b"(phase pairs)" not in old[5] and b"<256, 64, 8, 1" in old[5], old[5]
+    assert torch.equal(new[0], old[0]) and torch.equal(new[1], old[1])
+    for a, b in zip(new[2:5], old[2:5]):
+        assert relerr(a, b) <= 1e-6
+    ref = F.conv_transpose2d(gy.double(), wt.double(), None, 2, 1)
+    assert relerr(from_nhwc(new[1].cpu(), I).double(), ref) <= tol
+    ref2 = ref * torch.where(mask > 0, 1.0, 0.2) + res
+    assert relerr(from_nhwc(new[0].cpu(), I).double(), ref2) <= tol
+    assert relerr(new[2].cpu().double()[:, :I], ref.mean(dim=(2, 3))) <= 20 * tol
