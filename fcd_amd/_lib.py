@@ -177,7 +177,9 @@ def ptr(t: Optional[torch.Tensor]):
 
 
 def stream():
-    return torch.cuda.current_stream().cuda_stream
+    """The current HIP stream of the current device as a raw handle.  (torch.cuda.current_stream() builds a Stream
+    object through several layers of Python per call -- 8 us, some 300 times a step; this is the call under it.)"""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 class _Workspace:
@@ -188,7 +190,10 @@ class _Workspace:
 
     def get(self, nbytes: int, device) -> torch.Tensor:
         # one buffer per (device, stream): work on the side stream (ops.SideWork) must not share slabs with the chain
-        key = (torch.device(device).index, torch.cuda.current_stream(device).cuda_stream)
+        idx = device.index if isinstance(device, torch.device) else torch.device(device).index
+        if idx is None:
+            idx = torch._C._cuda_getDevice()
+        key = (idx, torch._C._cuda_getCurrentRawStream(idx))
         b = self.buf.get(key)
         if b is None or b.numel() < nbytes:
             b = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)

@@ -187,6 +187,7 @@ class FCDSolver(nn.Module):
         self._scheds = None
         self.pair_g_calls = True                    # G step: the four generator calls as two paired-batch calls
         self.pair_d_calls = True                    # D step: D(x_real) and D(x_fake) as one paired-batch call
+        self._param_lists = {}                      # _set_requires_grad: id(module) -> (module, parameters)
         # train_step only (training_step called by hand keeps the reference's own sequence):
         self.share_generator_forward = True         # the D step's G(x_real, c_trg) IS the G step's first generator call
         self.skip_unused_d_forward = True           # D(x_reconst_id) (reference :358) feeds nothing unless use_feats
@@ -449,14 +450,26 @@ class FCDSolver(nn.Module):
             opt.step()
         opt.arena.zero_grad()
 
+    def _set_requires_grad(self, module, flag: bool) -> None:
+        """``module.requires_grad_(flag)`` over a cached parameter list: ``nn.Module.requires_grad_`` walks the module
+        tree (named_modules / named_parameters) on every call, four times per step -- about a millisecond of host time.
+        The list is rebuilt when the module's parameter count changes."""
+        hit = self._param_lists.get(id(module))
+        if hit is None or hit[0] is not module:
+            hit = (module, list(module.parameters()))
+            self._param_lists[id(module)] = hit
+        for p in hit[1]:
+            if p.requires_grad != flag:
+                p.requires_grad_(flag)
+
     def _run_optimizer(self, batch, batch_idx, optimizer_idx, step: bool):
         """What Lightning does per optimizer: toggle, closure (training_step + backward), step, zero_grad."""
         opt = self.optimizers()[optimizer_idx]
         if optimizer_idx == 0:
             self._flush_pending()
         mine, other = (self.D, self.G) if optimizer_idx == 0 else (self.G, self.D)
-        other.requires_grad_(False)
-        mine.requires_grad_(True)
+        self._set_requires_grad(other, False)
+        self._set_requires_grad(mine, True)
         try:
             loss = self.training_step(batch, batch_idx, optimizer_idx)
             if loss is not None:
@@ -499,7 +512,7 @@ class FCDSolver(nn.Module):
             else:
                 opt.zero_grad(set_to_none=True)
         finally:
-            other.requires_grad_(True)
+            self._set_requires_grad(other, True)
         return loss
 
     def train_step(self, batch, batch_idx: int = 0, force_g: bool = False):
@@ -519,7 +532,7 @@ class FCDSolver(nn.Module):
                 # of the G step).  Here the call is made ONCE, as half of the G step's first paired call, with its graph
                 # kept for the G step; the D step takes the detached output.  repeat_first_group gives the tracked
                 # running statistics the D step's update as well, so they see five reference calls per step.
-                self.G.requires_grad_(True)
+                self._set_requires_grad(self.G, True)
                 with self.G.sample_groups(2), self.G.repeat_first_group(1):
                     self._shared_fake = self.G(torch.cat([x_real, x_real]), torch.cat([c_trg, c_org]))
             d_loss = self._run_optimizer(batch, batch_idx, 0, True)
