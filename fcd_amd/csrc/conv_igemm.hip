@@ -1741,7 +1741,9 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3p_kernel(const WgradArgs p, 
   constexpr int A_PLANE = KT * A_ROW, B_PLANE = KT * B_ROW;
   static_assert(NP >= 1 && NP <= 3, "planes");
   constexpr int STAGE = NP * (A_PLANE + B_PLANE);
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+  // (64-column wave tiles: the direct epilogue re-deals 32 x 64 floats per wave through these bytes)
+  constexpr int SMEM_BYTES = (WTN == 64 && 2 * STAGE < 8 * 32 * 64 * 4) ? 8 * 32 * 64 * 4 : 2 * STAGE;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1982,6 +1984,46 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3p_kernel(const WgradArgs p, 
     // no split-K: the tile holds final sums.  Column (i / 4, tap, i % 4) -> dw[o][i][tap]; the same value the slab +
     // wgrad_reduce_kernel pair would store (0 + v, then dw + v when accumulating): same bits, one pass over dw less
     float* __restrict__ dw = p.dw;
+    if constexpr (WTN == 64) {
+      if (ntap == 16 && p.I % 4 == 0 && ((unsigned long long)dw & 15ull) == 0) {
+        // A wave's 64 columns are the 16 taps of four channels: 256 contiguous bytes of dw[o].  Through LDS (the operand
+        // stages are free now: every wave passed the K loop's last barrier) the 32 x 64 sub-tile is re-dealt so that a
+        // lane holds four consecutive taps -- 16-byte loads and stores, four whole rows per wave instruction -- instead
+        // of 4-byte accesses 64 bytes apart.  Same values, same order of the one addition: same bits.
+        float* stg = reinterpret_cast<float*>(smem) + wave * (32 * 64);
+        const int col0 = tn * BN + wn * WTN;
+        const int ci0 = (col0 >> 6) * 4;                    // first of this wave's four channels
+        if (col0 < p.ND) {
+#pragma unroll
+          for (int mi = 0; mi < TM; ++mi) {
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+              const int c = ni * 32 + lr;                   // column in the wave's 64: channel c & 3, tap c >> 2
+#pragma unroll
+              for (int r = 0; r < 16; ++r)
+                stg[((r & 3) + 8 * (r >> 2) + 4 * lh) * 64 + (c & 3) * 16 + (c >> 2)] = 0.f + acc[mi][ni][r] * isc;
+            }
+            // (a wave's own LDS writes and reads: in order, no barrier needed)
+            const int j = lane & 15;                        // float4 j of a row: channel j >> 2, taps 4 (j & 3) ..
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              const int row = (lane >> 4) + 4 * k;
+              const int o = tm * BM + wm * WTM + mi * 32 + row;
+              if (o < p.O) {
+                float4* g = reinterpret_cast<float4*>(dw + ((long)o * p.I + ci0 + (j >> 2)) * 16 + 4 * (j & 3));
+                float4 v = *reinterpret_cast<const float4*>(stg + row * 64 + 4 * j);
+                if (p.accumulate) {
+                  const float4 u = *g;
+                  v = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
+                }
+                *g = v;
+              }
+            }
+          }
+        }
+        return;
+      }
+    }
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi)
 #pragma unroll

@@ -1078,7 +1078,8 @@ def test_gather_register_staged_f16x2(dev, fam, geom):
 
 @pytest.mark.parametrize("fam", [pytest.param((2, 1e-5), id="fp32x3"), pytest.param((3, 1e-6), id="fp32x2")])
 @pytest.mark.parametrize("shape", [(2048, 1024, 4, 2, 1, 8, 4, 4), (1024, 512, 4, 2, 1, 3, 8, 8), (48, 10, 4, 2, 1, 2, 8, 8),
-                                   (300, 36, 3, 1, 1, 2, 9, 7), (72, 20, 4, 2, 1, 5, 6, 10)])
+                                   (300, 36, 3, 1, 1, 2, 9, 7), (72, 20, 4, 2, 1, 5, 6, 10), (100, 24, 4, 2, 1, 3, 6, 6),
+                                   (260, 68, 4, 2, 1, 2, 4, 8)])
 def test_wgrad_direct_equals_slab_and_reduce(dev, shape, fam, monkeypatch):
     """conv_wgrad_x3p_kernel without split-K writes (or accumulates into) the parameter layout dw[O][I][KH][KW] itself --
     columns ordered (channel group, tap, channel) so that a wave stores whole 256-byte runs -- instead of a slab that
