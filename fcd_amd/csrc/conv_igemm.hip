@@ -4058,7 +4058,7 @@ static int halo12w_plan(const FcdWgradDesc* d, int* rows, int* R, int* nch, int*
 
 // The halo form of the 3x3 weight gradient on 32-pixel-wide images under FCD_PREC_BF16X3 (wgrad3_halo_x3_kernel):
 // number of slabs (= splits over whole images), or 0; *ipS = images per split.
-static int halo3w_plan(const FcdWgradDesc* d, int* ipS, int* mode = nullptr) {
+static int halo3w_plan(const FcdWgradDesc* d, int* ipS, int* mode = nullptr, bool h2 = true) {
   if (d->splitk > 0 || (d->precision != FCD_PREC_BF16X3 && d->precision != FCD_PREC_F16X2 && d->precision != FCD_PREC_F16) ||
       getenv("FCD_NO_WGRAD3"))
     return 0;
@@ -4069,7 +4069,8 @@ static int halo3w_plan(const FcdWgradDesc* d, int* ipS, int* mode = nullptr) {
     images = d->N;
     if (mode) *mode = 0;
   } else if (d->KH == 4 && d->KW == 4 && d->stride == 2 && d->pad == 1 && (d->GW == 32 || d->GW == 64) && d->BW == 2 * d->GW &&
-             d->BH == 2 * d->GH && !getenv("FCD_NO_WGRAD4")) {
+             d->BH == 2 * d->GH && h2 && !getenv("FCD_NO_WGRAD4")) {
+    // (scaled-fp16 forms only: with three bf16 planes and six MFMAs per group the split-once kernel is level or ahead)
     // MODE 1 of the kernel: 2 x 2 taps over the four parities of the input, 32-column halves of the gradient rows
     blocks = (long)(d->OP / 64) * (4 * d->IP / 64);
     images = (long)d->N * (d->GW / 32);
@@ -4129,7 +4130,9 @@ extern "C" size_t fcd_wgrad_workspace_bytes(const FcdWgradDesc* d) {
   int halves;
   if (!halo) halo = halo12w_plan(d, &rows, &R, &nch, &halves);
   if (!halo) halo = halo3w_plan(d, &rows);
-  return (size_t)(halo ? halo : resolve_wgrad_splitk(d)) * d->O * d->KH * d->KW * d->IP * sizeof(float);
+  // (MODE 1 of the halo kernel is taken only when both maxima are attached: room for either choice)
+  const int slabs = (halo && d->KH == 4) ? std::max(halo, resolve_wgrad_splitk(d)) : halo ? halo : resolve_wgrad_splitk(d);
+  return (size_t)slabs * d->O * d->KH * d->KW * d->IP * sizeof(float);
 }
 
 extern "C" int fcd_conv_wgrad(const FcdWgradDesc* d, const float* gsmall, const float* xbig, float* dw,
@@ -4203,7 +4206,7 @@ extern "C" int fcd_conv_wgrad(const FcdWgradDesc* d, const float* gsmall, const 
                          (size_t)a.P * a.OP * 4, (size_t)a.N * a.BH * a.BW * a.IP * 4);
     }
     rc = fcd_check_launch("conv_wgrad");
-  } else if (int ipS = 0, mode3 = 0, slabs3 = halo3w_plan(d, &ipS, &mode3); slabs3) {
+  } else if (int ipS = 0, mode3 = 0, slabs3 = halo3w_plan(d, &ipS, &mode3, want_h2); slabs3) {
     a.splitk = slabs3;
     const int ncb = (mode3 ? 4 : 1) * d->IP / 64;
     dim3 grid((d->OP / 64) * ncb, slabs3);
