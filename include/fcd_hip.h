@@ -182,8 +182,9 @@ int fcd_pack_weight_adj(const float* w, float* packed, int O, int OP, int I, int
 int fcd_conv_wants_split_weights(const FcdConvDesc* d);
 /* Weight operand the convolution described by d takes: 0 = fp32 packs (fcd_pack_weight_fwd / _adj), 1 = three bf16
  * planes (_x3), 2 = two fp16 planes of the scaled weights (_h2; FCD_PREC_F16X2 wherever BF16X3 would take format 1).
- * 3 = fp32 packs as for 0, and the kernel (the 7x7 halo forms, which split their operands themselves) takes the
- * two-fp16-piece form if a_amax and w_amax are both set (FCD_PREC_F16X2 only; without them it runs as BF16X3).
+ * 3 = fp32 packs as for 0, and the kernel (the 7x7 halo forms and the register-staged form of the layers with few
+ * output rows -- 128- / 64-row tiles of 128 channels, Cin a multiple of 32 -- which split their operands themselves) takes
+ * the two-fp16-piece form if a_amax and w_amax are both set (FCD_PREC_F16X2 only; without them it runs as BF16X3).
  * No reference counterpart (cuDNN chooses its own operand formats). */
 int fcd_conv_weight_format(const FcdConvDesc* d);
 /* FCD_PREC_F16X2 weight operands: [plane h | plane l][row][K] fp16 of s*w, s the power of two derived from *w_amax
