@@ -1289,10 +1289,14 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
   // (sums of v - ssh and (v - ssh)^2, ssh = the lane's first value of the column: keeps the variance of a
   // channel with |mean| >> std out of the fp32 rounding of sum v^2; undone in double below)
   float omax = 0.f;          // max |stored value| of this thread (out_amax)
-  float ssum[TN], qsum[TN], ssh[TN];
-  int scnt[TN];
+  // (PP: one set of sums per 32-row block, as the 256 x 64 tile's 32-row waves write them: the statistics keep their bits)
+  constexpr int TMS = PP ? TM : 1;
+  float ssum[TMS][TN], qsum[TMS][TN], ssh[TMS][TN];
+  int scnt[TMS][TN];
 #pragma unroll
-  for (int ni = 0; ni < TN; ++ni) { ssum[ni] = qsum[ni] = ssh[ni] = 0.f; scnt[ni] = 0; }
+  for (int si = 0; si < TMS; ++si)
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) { ssum[si][ni] = qsum[si][ni] = ssh[si][ni] = 0.f; scnt[si][ni] = 0; }
 #pragma unroll
   for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
@@ -1339,34 +1343,39 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
           omax = fmaxf(omax, fabsf(v[r]));
         }
       if (p.stats) {
+        const int si = PP ? mi : 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           if (off[r] >= 0) {
-            if (scnt[ni] == 0) ssh[ni] = v[r];
-            ++scnt[ni];
-            const float dv = v[r] - ssh[ni];
-            ssum[ni] += dv;
-            qsum[ni] += dv * dv;
+            if (scnt[si][ni] == 0) ssh[si][ni] = v[r];
+            ++scnt[si][ni];
+            const float dv = v[r] - ssh[si][ni];
+            ssum[si][ni] += dv;
+            qsum[si][ni] += dv * dv;
           }
       }
     }
   if (p.stats) {
-    const int m0 = tm * BM + wm * WTM;
-    if (m0 < p.M) {
-      const int n = m0 / ghw, local = (m0 - n * ghw) / WTM;
-      const long chunk = (long)n * p.nphase * p.stats_cpp + (long)phase * p.stats_cpp + local;
 #pragma unroll
-      for (int ni = 0; ni < TN; ++ni) {
-        const double shd = (double)ssh[ni], cn = (double)scnt[ni];
-        double s2 = (double)ssum[ni] + cn * shd;
-        double q2 = (double)qsum[ni] + 2.0 * shd * (double)ssum[ni] + cn * shd * shd;
-        s2 += __shfl_xor(s2, 32);
-        q2 += __shfl_xor(q2, 32);
-        const int co = PP ? ni * 32 + lr : tn * BN + wn * WTN + ni * 32 + lr;
-        if (lh == 0 && co < p.CoutP) {
-          double* d2 = p.stats + (chunk * p.CoutP + co) * 2;
-          d2[0] = s2;
-          d2[1] = q2;
+    for (int si = 0; si < TMS; ++si) {
+      constexpr int SROWS = PP ? 32 : WTM;              // rows behind one set of sums
+      const int m0 = tm * BM + wm * WTM + si * 32;
+      if (m0 < p.M) {
+        const int n = m0 / ghw, local = (m0 - n * ghw) / SROWS;
+        const long chunk = (long)n * p.nphase * p.stats_cpp + (long)phase * p.stats_cpp + local;
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+          const double shd = (double)ssh[si][ni], cn = (double)scnt[si][ni];
+          double s2 = (double)ssum[si][ni] + cn * shd;
+          double q2 = (double)qsum[si][ni] + 2.0 * shd * (double)ssum[si][ni] + cn * shd * shd;
+          s2 += __shfl_xor(s2, 32);
+          q2 += __shfl_xor(q2, 32);
+          const int co = PP ? ni * 32 + lr : tn * BN + wn * WTN + ni * 32 + lr;
+          if (lh == 0 && co < p.CoutP) {
+            double* d2 = p.stats + (chunk * p.CoutP + co) * 2;
+            d2[0] = s2;
+            d2[1] = q2;
+          }
         }
       }
     }
@@ -3836,7 +3845,7 @@ int fused_stats_chunks(const FcdConvDesc* d, bool h2) {
   gather_tile(d, bm, bn);
   if (bn == 16 || resolve_splitk(d) != 1) return 0;
   // rows per wave: the pre-split kernels run 4 x 2 waves on 128 rows, 4 x 2 or 8 x 1 on 256
-  const int wtm = ((gather_big_tile(d) && bn == 128) || (h2 && gather_pp(d))) ? 64 : wants_split_weights(d) ? 32 : gather_rs(d, bm, bn) ? 32 : gather_wave_rows(bm, bn);
+  const int wtm = (gather_big_tile(d) && bn == 128) ? 64 : wants_split_weights(d) ? 32 : gather_rs(d, bm, bn) ? 32 : gather_wave_rows(bm, bn);
   const long ghw = (long)d->GH * d->GW;
   if (ghw % wtm) return 0;
   return (int)(d->nphase * (ghw / wtm));
