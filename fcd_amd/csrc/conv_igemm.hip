@@ -105,6 +105,10 @@ struct WgradArgs {
   const float* g_amax;   // FCD_PREC_F16X2 (wgrad3_halo kernel): max |gs|, max |xb| (device scalars)
   const float* x_amax;
   unsigned* ovf;         // FCD_PREC_F16X2: the caller's sticky overflow word (fcd_set_overflow_flag) or NULL
+  const float* gs2;      // conv_wgrad_x3p_kernel, optional SECOND operand pair of the same geometry (fcd_conv_wgrad2): the K
+  const float* xb2;      // axis (pixels) runs over the first pair's P pixels (a multiple of 32) and then these P2 = N2 GH GW
+  int P2;                // ones: dw (+)= gs^T x + gs2^T x2 in one pass over dw; ktiles counts both
+  size_t gs2_bytes, xb2_bytes;
   int direct;            // conv_wgrad_x3p_kernel without split-K: columns ordered (i / 4, tap, i % 4) and written (or
                          // accumulated) straight into dw[O][I][KH][KW]; no slab, no wgrad_reduce_kernel
 };
@@ -1763,11 +1767,14 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3p_kernel(const WgradArgs p, 
   const int tn = tile % p.tiles_n, tm = tile / p.tiles_n;
   const int kt0 = ks * p.ktiles_per_split;
   const int kt1 = min(p.ktiles, kt0 + p.ktiles_per_split);
-  const int nk = kt1 - kt0;
+  // K segments (one, or two with a second operand pair): the block's K-tiles [kt0, kt1) of the concatenated pixel axis
+  // fall into segment 0 (the first P pixels, kts0 K-tiles) and / or segment 1; the accumulators run through both
+  const int kts0 = (p.P + KT - 1) / KT;
+  int nk = min(kt1, kts0) - kt0;                                 // segment 0's share (<= 0: none)
 
   // operand windows of this K range: from its first pixel row (gs) / first image (xb) on
-  const int px0 = kt0 * KT, n0 = __builtin_amdgcn_readfirstlane(px0 / (p.GH * p.GW));
-  const size_t gs_start = (size_t)px0 * p.OP * 4, xb_start = (size_t)n0 * p.BH * p.BW * p.IP * 4;
+  int px0 = min(kt0, kts0) * KT, n0 = __builtin_amdgcn_readfirstlane(px0 / (p.GH * p.GW));
+  size_t gs_start = (size_t)px0 * p.OP * 4, xb_start = (size_t)n0 * p.BH * p.BW * p.IP * 4;
   __amdgpu_buffer_rsrc_t rgs = __builtin_amdgcn_make_buffer_rsrc((char*)p.gs + gs_start, (short)0,
                                                                  (int)window_bytes(gs_bytes, gs_start), 0x00020000);
   __amdgpu_buffer_rsrc_t rxb = __builtin_amdgcn_make_buffer_rsrc((char*)p.xb + xb_start, (short)0,
@@ -1798,7 +1805,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3p_kernel(const WgradArgs p, 
     b_a[i] = rem / p.GW;
     b_b[i] = rem - b_a[i] * p.GW;
   }
-  const int prel = p.P - px0;                                    // pixels from the window's start to the end of the tensor
+  int prel = p.P - px0;                                          // pixels from the window's start to the end of the tensor
   // one K-tile = KT pixels further = step_n images + step_a rows + step_b columns (branch-free carries)
   const int step_n = KT / ghw, step_r = KT - step_n * ghw, step_a = step_r / p.GW, step_b = step_r - step_a * p.GW;
   u32x4 ra[AL], rb[BL];
@@ -1910,6 +1917,31 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3p_kernel(const WgradArgs p, 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = acc2[i][j][r] = 0.f;
 
+  constexpr int NPR = NP == 3 ? 6 : (NP == 2 ? 3 : 1);   // products per group
+  constexpr int NI = AL + BL, NMF = 2 * NPR * TM * TN; // items and MFMAs per K-tile
+  for (int seg = 0; seg < (p.gs2 != nullptr ? 2 : 1); ++seg) {
+  if (seg == 1) {
+    // the second operand pair: this block's K-tiles of it, windows and loader state from its first pixel on
+    const int k0 = max(kt0, kts0) - kts0;
+    nk = (kt1 - kts0) - k0;
+    px0 = k0 * KT;
+    n0 = __builtin_amdgcn_readfirstlane(px0 / ghw);
+    gs_start = (size_t)px0 * p.OP * 4;
+    xb_start = (size_t)n0 * p.BH * p.BW * p.IP * 4;
+    rgs = __builtin_amdgcn_make_buffer_rsrc((char*)p.gs2 + gs_start, (short)0, (int)window_bytes(p.gs2_bytes, gs_start), 0x00020000);
+    rxb = __builtin_amdgcn_make_buffer_rsrc((char*)p.xb2 + xb_start, (short)0, (int)window_bytes(p.xb2_bytes, xb_start), 0x00020000);
+    a_px = a_row;
+#pragma unroll
+    for (int i = 0; i < BL; ++i) {
+      b_px[i] = b_row + RPB * i;
+      const int bn = (px0 + b_px[i]) / ghw, rem = px0 + b_px[i] - bn * ghw;
+      b_n[i] = bn - n0;
+      b_a[i] = rem / p.GW;
+      b_b[i] = rem - b_a[i] * p.GW;
+    }
+    prel = p.P2 - px0;
+    __syncthreads();                   // (segment 0's last reads of the stages are behind every wave)
+  }
   if (nk > 0) {
     load_tile();
     store_tile(0);
@@ -1917,8 +1949,6 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3p_kernel(const WgradArgs p, 
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
-  constexpr int NPR = NP == 3 ? 6 : (NP == 2 ? 3 : 1);   // products per group
-  constexpr int NI = AL + BL, NMF = 2 * NPR * TM * TN; // items and MFMAs per K-tile
   for (int it = 0; it < nk; ++it) {
     const unsigned char* cur = smem + (it & 1) * STAGE;
     unsigned char* nxt = smem + ((it + 1) & 1) * STAGE;
@@ -1978,6 +2008,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3p_kernel(const WgradArgs p, 
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
+  }   // segments
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -4144,8 +4175,38 @@ extern "C" size_t fcd_wgrad_workspace_bytes(const FcdWgradDesc* d) {
   return (size_t)slabs * d->O * d->KH * d->KW * d->IP * sizeof(float);
 }
 
+// Shapes whose weight gradient can take a second operand pair (fcd_conv_wgrad2): what conv_wgrad_x3p_kernel serves under
+// FCD_PREC_BF16X3 -- more than 32 output channels, no halo form -- with a first pair of whole 32-pixel K-tiles.
+static bool wgrad2_ok(const FcdWgradDesc* d) {
+  if (d->precision != FCD_PREC_BF16X3 || d->O <= 32 || getenv("FCD_WGRAD_OLD")) return false;
+  if (((long)d->N * d->GH * d->GW) % 32 != 0) return false;
+  int rows, R, nch, halves, ipS;
+  if (halo7_plan(d, &rows, &R, &nch) || halo12w_plan(d, &rows, &R, &nch, &halves) || halo3w_plan(d, &ipS, nullptr, false)) return false;
+  return true;
+}
+extern "C" int fcd_conv_wgrad2_supported(const FcdWgradDesc* d) {
+  if (!d || validate_wgrad(d) != FCD_OK) return 0;
+  return wgrad2_ok(d) ? 1 : 0;
+}
+
+static int wgrad_impl(const FcdWgradDesc* d, const float* gsmall, const float* xbig, const float* gsmall2,
+                      const float* xbig2, int N2, float* dw, void* workspace, size_t workspace_bytes, void* stream);
+
 extern "C" int fcd_conv_wgrad(const FcdWgradDesc* d, const float* gsmall, const float* xbig, float* dw,
                               void* workspace, size_t workspace_bytes, void* stream) {
+  return wgrad_impl(d, gsmall, xbig, nullptr, nullptr, 0, dw, workspace, workspace_bytes, stream);
+}
+
+extern "C" int fcd_conv_wgrad2(const FcdWgradDesc* d, const float* gsmall, const float* xbig, const float* gsmall2,
+                               const float* xbig2, int N2, float* dw, void* workspace, size_t workspace_bytes, void* stream) {
+  FCD_REQUIRE(d != nullptr && gsmall2 && xbig2 && N2 > 0, "wgrad2: the second operand pair");
+  FCD_REQUIRE(validate_wgrad(d) == FCD_OK && wgrad2_ok(d),
+              "wgrad2: shape / precision without a two-segment form (fcd_conv_wgrad2_supported)");
+  return wgrad_impl(d, gsmall, xbig, gsmall2, xbig2, N2, dw, workspace, workspace_bytes, stream);
+}
+
+static int wgrad_impl(const FcdWgradDesc* d, const float* gsmall, const float* xbig, const float* gsmall2,
+                      const float* xbig2, int N2, float* dw, void* workspace, size_t workspace_bytes, void* stream) {
   FCD_REQUIRE(d != nullptr, "wgrad: null descriptor");
   FcdWgradDesc dd = *d;
   // FCD_PREC_F16X2: the two-plane forms need both maxima; without them (and for the shapes that have no such form)
@@ -4161,7 +4222,10 @@ extern "C" int fcd_conv_wgrad(const FcdWgradDesc* d, const float* gsmall, const 
   int rc = validate_wgrad(d);
   if (rc) return rc;
   FCD_REQUIRE(gsmall && xbig && dw, "wgrad: null tensor");
-  const size_t need = fcd_wgrad_workspace_bytes(d);
+  // (two operand pairs: split-K and the slabs are those of one pair of N + N2 images)
+  FcdWgradDesc dsum = dd;
+  dsum.N += N2;
+  const size_t need = fcd_wgrad_workspace_bytes(&dsum);
   if (workspace == nullptr || workspace_bytes < need) {
     fcd_set_error("wgrad: workspace %zu < %zu bytes", workspace_bytes, need);
     return FCD_EWORKSPACE;
@@ -4172,8 +4236,12 @@ extern "C" int fcd_conv_wgrad(const FcdWgradDesc* d, const float* gsmall, const 
   a.I = d->I; a.IP = d->IP; a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
   a.P = d->N * d->GH * d->GW;
   a.ND = d->KH * d->KW * d->IP;
-  a.splitk = resolve_wgrad_splitk(d);
-  a.ktiles = fcd_cdiv(a.P, 32);
+  a.gs2 = gsmall2; a.xb2 = xbig2;
+  a.P2 = N2 * d->GH * d->GW;
+  a.gs2_bytes = (size_t)a.P2 * d->OP * 4;
+  a.xb2_bytes = (size_t)N2 * d->BH * d->BW * d->IP * 4;
+  a.splitk = resolve_wgrad_splitk(&dsum);
+  a.ktiles = fcd_cdiv(a.P, 32) + fcd_cdiv(a.P2, 32);
   a.ktiles_per_split = fcd_cdiv(a.ktiles, a.splitk);
   a.splitk = fcd_cdiv(a.ktiles, a.ktiles_per_split);
   a.accumulate = d->accumulate;

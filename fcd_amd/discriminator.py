@@ -126,6 +126,14 @@ class Discriminator(nn.Module):
         self._g2 = ConvGeom(c_dim, cin, ks, 1, 0)
         self._grad_hook = None        # parallel.BucketedReducer while a data-parallel D step runs
         self.input_only = False       # input_grad_only(self): backward skips parameter gradients
+        # One weight-gradient launch per layer for the D step's two backward passes (ops.conv_wgrad2): whichever of the
+        # paired batch's backward and the gradient penalty's backward-of-backward autograd runs first leaves its operand
+        # pair per layer here, the other takes it into its own launch; whatever is left when backward ends is flushed by
+        # a callback.  FCD_MERGE_WGRAD=0: two launches per layer as before (A/B runs).
+        self.merge_wgrad = os.environ.get("FCD_MERGE_WGRAD", "1") != "0"
+        self._wgrad_stash = {}        # layer -> [(gz, u, sink)]
+        self._wgrad_flush_queued = False
+        self._wgrad_task = -1         # autograd graph task the stash belongs to
         self._wmax = WeightMaxima(self._convs)     # max |weight| of the six layers in one launch per optimizer step
 
     def _flat_params(self):
@@ -133,6 +141,43 @@ class Discriminator(nn.Module):
         for cv in self._convs:
             out += [cv.weight, cv.bias]
         return out + [self.conv1.weight, self.conv2.weight]
+
+    def _stash_wgrad(self, li, gz, u, sink) -> None:
+        """Leave layer ``li``'s weight-gradient operands for a later backward pass of the same ``backward()`` call."""
+        task = torch._C._current_graph_task_id()
+        if task != self._wgrad_task:
+            # a new backward call (whatever an aborted earlier one left behind is dropped with its graph)
+            self._wgrad_task, self._wgrad_stash, self._wgrad_flush_queued = task, {}, False
+        self._wgrad_stash.setdefault(li, []).append((gz, u, sink))
+        if not self._wgrad_flush_queued:
+            self._wgrad_flush_queued = True
+            torch.autograd.Variable._execution_engine.queue_callback(self._flush_wgrad_stash)
+
+    def _take_wgrad(self, li, wd, x, sink):
+        """The operand pair an earlier pass of this backward call left for layer ``li``, if this pass can take it into its
+        own launch (same gradient tensor, same geometry, a two-segment form for ``wd``), else None."""
+        if sink is None or not self._wgrad_stash or self._wgrad_task != torch._C._current_graph_task_id():
+            return None
+        pend = self._wgrad_stash.get(li)
+        if (pend and len(pend) == 1 and pend[0][2] is sink and tuple(pend[0][1].shape[1:]) == tuple(x.shape[1:])
+                and ops.conv_wgrad2_supported(wd)):
+            del self._wgrad_stash[li]
+            return pend[0]
+        return None
+
+    def _can_stash_wgrad(self, wd, sink, final: bool, scaled: bool) -> bool:
+        return bool(self.merge_wgrad and sink is not None and not final and not scaled and ops.conv_wgrad2_supported(wd))
+
+    def _flush_wgrad_stash(self) -> None:
+        """End of a backward call: operand pairs nobody took are turned into gradients by launches of their own."""
+        self._wgrad_flush_queued = False
+        stash, self._wgrad_stash = self._wgrad_stash, {}
+        prec_w = self.precision if self.wgrad_precision is None else self.wgrad_precision
+        for li, items in stash.items():
+            g = self._geoms[li]
+            for gz, u, sink in items:
+                wd = g.wgrad_desc(u.shape[0], u.shape[1], u.shape[2], precision=prec_w, accumulate=True)
+                ops.conv_wgrad(wd, gz, u, dw=sink)
 
     def forward(self, x):
         if not x.is_cuda:
@@ -270,11 +315,23 @@ class _DBackwardFn(torch.autograd.Function):
                 if h2 and prec_w in L.F16_FAMILY:
                     ops.set_wgrad_amax(wd, gamx[li], acts.amx[li])
                 bsink = grad_sink(cv.bias, gz.shape[3] == g.O)
+                # an operand pair the gradient penalty's pass left for this layer rides in the same launch; if that pass
+                # is still to come, this one leaves its pair instead (Discriminator.merge_wgrad)
+                scaled = h2 and prec_w in L.F16_FAMILY
+                extra = None if scaled else mod._take_wgrad(li, wd, a_in, sink)
+                if extra is not None:
+                    wfn = lambda: ops.conv_wgrad2(wd, gz, a_in, extra[0], extra[1], dw=sink)
+                elif mod._can_stash_wgrad(wd, sink, final, scaled):
+                    mod._stash_wgrad(li, gz, a_in, sink)
+                    wfn = lambda: None
+                else:
+                    wfn = lambda: ops.conv_wgrad(wd, gz, a_in, dw=sink)
                 # (results that come back as fresh tensors are sliced below, on this stream: those stay on it)
                 run = side.run if sink is not None and bsink is not None else (lambda fn, *keep: fn())
-                dw, bs = run(lambda: (ops.conv_wgrad(wd, gz, a_in, dw=sink),
+                dw, bs = run(lambda: (wfn(),
                                       ops.colsum(gz.numel() // gz.shape[3], gz, gz.shape[3], out=bsink,
-                                                 accumulate=bsink is not None)), gz, a_in)
+                                                 accumulate=bsink is not None)), gz, a_in,
+                             *(extra[:2] if extra is not None else ()))
                 grads[2 * li] = None if sink is not None else dw
                 if bsink is None:
                     grads[2 * li + 1] = bs if gz.shape[3] == g.O else bs[: g.O].contiguous()
@@ -345,7 +402,18 @@ class _DBackwardFn(torch.autograd.Function):
                 wd = g.wgrad_desc(n, u.shape[1], u.shape[2], precision=prec_w, accumulate=sink is not None)
                 if h2 and prec_w in L.F16_FAMILY:
                     ops.set_wgrad_amax(wd, gamx[li], uamx[li])
-                dw = side.run(lambda wd=wd, gz=gzs[li], u=u, sink=sink: ops.conv_wgrad(wd, gz, u, dw=sink), gzs[li], u)
+                scaled = h2 and prec_w in L.F16_FAMILY
+                extra = None if scaled else mod._take_wgrad(li, wd, u, sink)
+                if extra is not None:
+                    # the paired batch's pass left its operand pair for this layer: one launch, one pass over the gradient
+                    dw = side.run(lambda wd=wd, gz=gzs[li], u=u, sink=sink, e=extra: ops.conv_wgrad2(wd, gz, u, e[0], e[1], dw=sink),
+                                  gzs[li], u, extra[0], extra[1])
+                elif mod._can_stash_wgrad(wd, sink, final, scaled):
+                    # another pass of this backward call may produce the same gradient: it takes this pair along
+                    mod._stash_wgrad(li, gzs[li], u, sink)
+                    dw = None
+                else:
+                    dw = side.run(lambda wd=wd, gz=gzs[li], u=u, sink=sink: ops.conv_wgrad(wd, gz, u, dw=sink), gzs[li], u)
                 out[2 * li] = None if sink is not None else dw
             if needs[2 * li + 1] and grad_sink(mod._convs[li].bias, True) is None:
                 out[2 * li + 1] = torch.zeros_like(mod._convs[li].bias)

@@ -380,6 +380,39 @@ def conv_wgrad(d: WgradDesc, gsmall: torch.Tensor, xbig: torch.Tensor, dw: Optio
     return dw
 
 
+def conv_wgrad2_supported(d: WgradDesc) -> bool:
+    """True where ``conv_wgrad2`` has a kernel for the shape and precision of ``d``."""
+    return bool(L.load().fcd_conv_wgrad2_supported(C.byref(d)))
+
+
+def conv_wgrad2(d: WgradDesc, gsmall: torch.Tensor, xbig: torch.Tensor, gsmall2: torch.Tensor, xbig2: torch.Tensor,
+                dw: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``conv_wgrad`` over two operand pairs of one geometry (``d.N`` and ``gsmall2.shape[0]`` images) in one pass over
+    ``dw``: ``dw (+)= gsmall^T xbig + gsmall2^T xbig2``."""
+    lib = L.load()
+    n2 = gsmall2.shape[0]
+    if tuple(gsmall.shape) != (d.N, d.GH, d.GW, d.OP) or tuple(xbig.shape) != (d.N, d.BH, d.BW, d.IP):
+        raise RuntimeError("conv_wgrad2: first operand pair does not match the descriptor")
+    if tuple(gsmall2.shape) != (n2, d.GH, d.GW, d.OP) or tuple(xbig2.shape) != (n2, d.BH, d.BW, d.IP):
+        raise RuntimeError("conv_wgrad2: second operand pair does not match the descriptor's geometry")
+    if dw is None:
+        if d.accumulate:
+            raise RuntimeError("conv_wgrad2: accumulate needs dw")
+        dw = torch.empty((d.O, d.I, d.KH, d.KW), dtype=torch.float32, device=xbig.device)
+    elif dw.numel() != d.O * d.I * d.KH * d.KW:
+        raise RuntimeError("conv_wgrad2: dw size")
+    for t, nm in ((gsmall, "gsmall"), (xbig, "xbig"), (gsmall2, "gsmall2"), (xbig2, "xbig2"), (dw, "dw")):
+        L.require_gpu_tensor(t, nm)
+    n1 = d.N
+    d.N = n1 + n2
+    need = lib.fcd_wgrad_workspace_bytes(C.byref(d))
+    d.N = n1
+    wp, wn = _ws(need, xbig.device)
+    check(lib.fcd_conv_wgrad2(C.byref(d), ptr(gsmall), ptr(xbig), ptr(gsmall2), ptr(xbig2), n2, ptr(dw), wp, wn, stream()),
+          "conv_wgrad2")
+    return dw
+
+
 def pack_weight_fwd(w: torch.Tensor, g: ConvGeom) -> torch.Tensor:
     L.require_gpu_tensor(w, "weight")
     out = torch.empty((g.O, g.k, g.k, g.IP), dtype=torch.float32, device=w.device)

@@ -1200,3 +1200,34 @@ def test_gather_phase_pairs_equal_single_phases(dev, geom, fam, monkeypatch):
     ref2 = ref * torch.where(mask > 0, 1.0, 0.2) + res
     assert relerr(from_nhwc(new[0].cpu(), I).double(), ref2) <= tol
     assert relerr(new[2].cpu().double()[:, :I], ref.mean(dim=(2, 3))) <= 20 * tol
+
+
+@pytest.mark.parametrize("shape", [(2048, 1024, 8, 4, 4, 4), (512, 256, 4, 2, 16, 16), (128, 64, 2, 2, 32, 32), (72, 20, 2, 3, 8, 8),
+                                   (1024, 512, 32, 16, 8, 8)])
+def test_wgrad_two_operand_pairs(dev, shape):
+    """fcd_conv_wgrad2: the split-once kernel's K loop over two operand pairs of one geometry (the discriminator's paired
+    batch and its gradient-penalty batch) -- one pass over dw, fresh and accumulating, direct and split-K shapes, a ragged
+    last K-tile in the second pair -- against torch in float64 and against two accumulating single-pair calls."""
+    from fcd_amd import ops
+    O, I, n1, n2, h, w = shape
+    g = ops.ConvGeom(O, I, 4, 2, 1)
+    gen = torch.Generator().manual_seed(61)
+    xs = [torch.randn(n, I, h, w, generator=gen) for n in (n1, n2)]
+    sh, sw = g.small_hw(h, w)
+    gys = [torch.randn(n, O, sh, sw, generator=gen) * s for n, s in ((n1, 1.0), (n2, 3.0))]
+    xd = [to_nhwc(x, g.IP).to(dev) for x in xs]
+    gd = [to_nhwc(gy, g.OP).to(dev) for gy in gys]
+    d = g.wgrad_desc(n1, h, w, precision=2)
+    assert ops.conv_wgrad2_supported(d)
+    got = ops.conv_wgrad2(d, gd[0], xd[0], gd[1], xd[1])
+    ref = sum(torch.nn.grad.conv2d_weight(x.double(), (O, I, 4, 4), gy.double(), stride=2, padding=1) for x, gy in zip(xs, gys))
+    assert relerr(got, ref) <= 1e-5
+    two = ops.conv_wgrad(g.wgrad_desc(n1, h, w, precision=2), gd[0], xd[0])
+    ops.conv_wgrad(g.wgrad_desc(n2, h, w, precision=2, accumulate=True), gd[1], xd[1], dw=two)
+    assert relerr(got, two) <= 2e-6
+    acc = torch.full_like(got, 0.125)
+    ops.conv_wgrad2(g.wgrad_desc(n1, h, w, precision=2, accumulate=True), gd[0], xd[0], gd[1], xd[1], dw=acc)
+    assert relerr(acc - 0.125, ref) <= 1e-4
+    # shapes and precisions without the two-segment form say so
+    assert not ops.conv_wgrad2_supported(g.wgrad_desc(n1, h, w, precision=0))
+    assert not ops.conv_wgrad2_supported(ops.ConvGeom(16, I, 4, 2, 1).wgrad_desc(n1, h, w, precision=2))

@@ -16,6 +16,7 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import relerr
 from oracle import fcd_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -74,7 +75,7 @@ def sample_errors(grad, tag, name, sc, which=""):
             float((got - o64).abs().max()) / amax, sc["ref_fp32_vs_fp64_grad_maxabs_rel"][tag][name])
 
 
-def check_grads(net, tag, sc, prec):
+def check_grads(net, tag, sc, prec, label=""):
     FACTOR, FACTOR_MAX = FACTORS[prec]
     report, worst, failures = {}, 0.0, []
     for name, p in net.named_parameters():
@@ -95,7 +96,7 @@ def check_grads(net, tag, sc, prec):
         report[name] = entry
     try:
         os.makedirs(OUT_DIR, exist_ok=True)
-        with open(os.path.join(OUT_DIR, f"full_parity_{tag}_{prec}.json"), "w") as f:
+        with open(os.path.join(OUT_DIR, f"full_parity_{tag}_{prec}{label}.json"), "w") as f:
             json.dump({"precision": prec, "step": tag, "factor_norm": FACTOR, "factor_elementwise": FACTOR_MAX,
                        "worst_error_over_bar": worst,
                        "errors_vs_fp64_oracle": report}, f, indent=1)
@@ -133,6 +134,38 @@ def test_full_g_step(full, prec):
     print("full G-step", prec, ": worst error / bar =", check_grads(s.G, "g", sc, prec))
 
 
+@pytest.mark.parametrize("prec", ["fp32x2", "fp32x3"])
+def test_full_d_step_arena_merged_weight_gradients(full, prec, monkeypatch):
+    """The training path of the D step: gradients accumulated by the kernels straight into the arena, the paired batch's
+    and the gradient penalty's weight gradients of every layer in ONE launch over two operand pairs (fcd_conv_wgrad2,
+    Discriminator.merge_wgrad).  Same parity bars against the fp64 oracle as the autograd path; against the two-launch
+    form (merge_wgrad off) only the order of fp32 sums differs."""
+    from fcd_amd import ops
+    sc, make, b, alpha = full
+    grads, calls = {}, {}
+    for merged in (True, False):
+        s = make(prec)
+        s.optimizers()
+        s.alpha_override = alpha
+        s.D.merge_wgrad = merged
+        s.G.requires_grad_(False)
+        n2 = [0]
+        orig = ops.conv_wgrad2
+        monkeypatch.setattr(ops, "conv_wgrad2", lambda *a, **k: (n2.__setitem__(0, n2[0] + 1), orig(*a, **k))[1])
+        loss = s.training_step(b, 0, 0)
+        with s.arenas[0].accumulating():
+            loss.backward()
+        monkeypatch.setattr(ops, "conv_wgrad2", orig)
+        calls[merged] = n2[0]
+        assert not s.D._wgrad_stash                      # nothing left behind
+        if merged:
+            print("full D-step, arena, merged weight gradients", prec, ": worst error / bar =", check_grads(s.D, "d", sc, prec, "_arena_merged"))
+        grads[merged] = {n: p.grad.clone() for n, p in s.D.named_parameters()}
+    assert calls[True] == 6 and calls[False] == 0        # every layer of D took the two-pair launch
+    for n in grads[True]:
+        assert relerr(grads[True][n], grads[False][n]) <= 5e-6, n
+
+
 def test_full_steps_with_scaled_fp16_discriminator(full):
     """FCDSolver.d_scaled_fp16 (off by default: measured level with BF16X3): the discriminator on the two-piece fp16
     kernels under fp32x2, its activations' and gradients' maxima handed from convolution to convolution through
@@ -149,7 +182,7 @@ def test_full_steps_with_scaled_fp16_discriminator(full):
     s.training_step(b, 0, 0).backward()
     for k, v in sc["d_losses64"].items():
         assert abs(float(s.loss_dict[k]) - v) <= 1e-4 * max(1.0, abs(v)), k
-    print("full D-step, D on the fp16 x 2 kernels: worst error / bar =", check_grads(s.D, "d", sc, "fp32x2"))
+    print("full D-step, D on the fp16 x 2 kernels: worst error / bar =", check_grads(s.D, "d", sc, "fp32x2", "_d_scaled_fp16"))
     s.check_overflow()
     s.D.zero_grad(set_to_none=True)
     s.G.requires_grad_(True)
@@ -158,7 +191,7 @@ def test_full_steps_with_scaled_fp16_discriminator(full):
     s.training_step(b, 0, 1).backward()
     for k, v in sc["g_losses64"].items():
         assert abs(float(s.loss_dict[k]) - v) <= 1e-4 * max(1.0, abs(v)), k
-    print("full G-step, D on the fp16 x 2 kernels: worst error / bar =", check_grads(s.G, "g", sc, "fp32x2"))
+    print("full G-step, D on the fp16 x 2 kernels: worst error / bar =", check_grads(s.G, "g", sc, "fp32x2", "_d_scaled_fp16"))
     s.check_overflow()
 
 
