@@ -76,7 +76,7 @@ PROTOTYPES = {
     "fcd_wgrad_workspace_bytes": (_Z, [C.POINTER(WgradDesc)]),
     "fcd_conv_wgrad": (_I, [C.POINTER(WgradDesc), _P, _P, _P, _P, _Z, _P]),
     "fcd_conv_wgrad2_supported": (_I, [C.POINTER(WgradDesc)]),
-    "fcd_conv_wgrad2": (_I, [C.POINTER(WgradDesc), _P, _P, _P, _P, _I, _P, _P, _Z, _P]),
+    "fcd_conv_wgrad2": (_I, [C.POINTER(WgradDesc), _P, _P, _P, _P, _I, _P, _P, _P, _P, _Z, _P]),
     "fcd_pack_weight_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "fcd_pack_weight_adj": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "fcd_conv_wants_split_weights": (_I, [C.POINTER(ConvDesc)]),

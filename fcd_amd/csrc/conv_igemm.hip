@@ -109,6 +109,9 @@ struct WgradArgs {
   const float* xb2;      // axis (pixels) runs over the first pair's P pixels (a multiple of 32) and then these P2 = N2 GH GW
   int P2;                // ones: dw (+)= gs^T x + gs2^T x2 in one pass over dw; ktiles counts both
   size_t gs2_bytes, xb2_bytes;
+  int N2;                // images of the second pair (wgrad3_halo_x3_kernel walks N + N2 images)
+  const float* g_amax2;  // the second pair's maxima (scaled-fp16 forms: one scale per operand from the larger of the two)
+  const float* x_amax2;
   int direct;            // conv_wgrad_x3p_kernel without split-K: columns ordered (i / 4, tap, i % 4) and written (or
                          // accumulated) straight into dw[O][I][KH][KW]; no slab, no wgrad_reduce_kernel
 };
@@ -215,14 +218,19 @@ __host__ __device__ __forceinline__ float pow2_scale_bits(unsigned amax_bits) {
 }
 // The maxima arrive as FCD_AMAX_SLOTS partial maxima, one per block of the producing kernel (norm.hip: block_absmax);
 // every lane of the calling wave must be active (4 KB per wave, from L2).
-__device__ __forceinline__ float pow2_scale(const float* amax) {
+// (amax2: the maxima of a second tensor that shares the scale -- fcd_conv_wgrad2's second operand pair -- or null)
+__device__ __forceinline__ float pow2_scale(const float* amax, const float* amax2 = nullptr) {
   static_assert(FCD_AMAX_SLOTS == 1024, "four float4 per lane");
-  const float4* p = reinterpret_cast<const float4*>(amax) + (threadIdx.x & 63);
   float m = 0.f;
+  for (int t = 0; t < 2; ++t) {
+    const float* src = t ? amax2 : amax;
+    if (src == nullptr) continue;
+    const float4* p = reinterpret_cast<const float4*>(src) + (threadIdx.x & 63);
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const float4 v = p[k * 64];
-    m = fmaxf(fmaxf(fmaxf(m, v.x), v.y), fmaxf(v.z, v.w));
+    for (int k = 0; k < 4; ++k) {
+      const float4 v = p[k * 64];
+      m = fmaxf(fmaxf(fmaxf(m, v.x), v.y), fmaxf(v.z, v.w));
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
@@ -1848,7 +1856,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_x3p_kernel(const WgradArgs p, 
   for (int i = 0; i < BL; ++i) b_st[i] = NP * A_PLANE + plane_off(b_row + RPB * i, b_c4 >> 1, B_ROW) + 8 * (b_c4 & 1);
   float sg = 1.f, sx = 1.f;
   float om = 0.f;      // max |scaled operand| this thread split (ovf_report)
-  if constexpr (NP <= 2) { sg = pow2_scale(p.g_amax); sx = pow2_scale(p.x_amax); }
+  if constexpr (NP <= 2) { sg = pow2_scale(p.g_amax, p.g_amax2); sx = pow2_scale(p.x_amax, p.x_amax2); }
   auto split_store = [&](const u32x4 v, unsigned char* dst, int plane_bytes, float sc) {
     if constexpr (NP == 1) {
       uint2 h2;
@@ -2913,45 +2921,56 @@ __global__ __launch_bounds__(64 * W3_WAVES) void wgrad3_halo_x3_kernel(const Wgr
   const int cb = blk % ncb, ob = blk / ncb;
   // (MODE 1: "images" are the 32-column halves of the gradient rows, hpi per real image)
   const int hpi = MODE ? p.GW / 32 : 1;
-  const int n_begin = split * ipS, n_end = min(p.N * hpi, n_begin + ipS);
+  // (fcd_conv_wgrad2: the images of a second operand pair follow the first pair's)
+  const int nv1 = p.N * hpi, nv = nv1 + (p.gs2 ? p.N2 * hpi : 0);
+  const int n_begin = split * ipS, n_end = min(nv, n_begin + ipS);
   const int GH = p.GH;
-  const int r_begin = n_begin / hpi;                      // first real image of this split
+  // first real image of this split in either pair
+  const int r_begin = min(n_begin, nv1) / hpi, r2_begin = max(n_begin - nv1, 0) / hpi;
   // MODE 1: parity (py, pq) and the real channel block of this workgroup's 64 virtual channels
   const int cpb = MODE ? p.IP / 64 : 1, par = MODE ? cb / cpb : 0, py = par >> 1, pq = par & 1, cbr = MODE ? cb - par * cpb : cb;
-  // operand windows: from this split's first image on
-  const size_t gs_start = (size_t)r_begin * GH * p.GW * p.OP * 4, xb_start = (size_t)r_begin * p.BH * p.BW * p.IP * 4;
-  __amdgpu_buffer_rsrc_t rgs = __builtin_amdgcn_make_buffer_rsrc((char*)p.gs + gs_start, (short)0,
-                                                                 (int)window_bytes(gs_bytes, gs_start), 0x00020000);
-  __amdgpu_buffer_rsrc_t rxb = __builtin_amdgcn_make_buffer_rsrc((char*)p.xb + xb_start, (short)0,
-                                                                 (int)window_bytes(xb_bytes, xb_start), 0x00020000);
+  // operand windows: from this split's first image on, per pair
+  const size_t img_g = (size_t)GH * p.GW * p.OP * 4, img_x = (size_t)p.BH * p.BW * p.IP * 4;
+  const size_t gs_start = (size_t)r_begin * img_g, xb_start = (size_t)r_begin * img_x;
+  const __amdgpu_buffer_rsrc_t rgs1 = __builtin_amdgcn_make_buffer_rsrc((char*)p.gs + gs_start, (short)0,
+                                                                        (int)window_bytes(gs_bytes, gs_start), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rxb1 = __builtin_amdgcn_make_buffer_rsrc((char*)p.xb + xb_start, (short)0,
+                                                                        (int)window_bytes(xb_bytes, xb_start), 0x00020000);
+  const size_t gs2_start = (size_t)r2_begin * img_g, xb2_start = (size_t)r2_begin * img_x;
+  const bool two = p.gs2 != nullptr;
+  const __amdgpu_buffer_rsrc_t rgs2 = __builtin_amdgcn_make_buffer_rsrc(
+      (char*)(two ? p.gs2 : p.gs) + (two ? gs2_start : 0), (short)0, two ? (int)window_bytes(p.gs2_bytes, gs2_start) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rxb2 = __builtin_amdgcn_make_buffer_rsrc(
+      (char*)(two ? p.xb2 : p.xb) + (two ? xb2_start : 0), (short)0, two ? (int)window_bytes(p.xb2_bytes, xb2_start) : 0, 0x00020000);
+  // the image the loop is at: its pair's windows, its real image relative to the window, its 32-column half
+  __amdgpu_buffer_rsrc_t rgs = rgs1, rxb = rxb1;
+  int ri = 0, half = 0;
 
   // float4 f of an input row = pixel f >> 4 (of 34), channels 64 cb + 4 (f & 15) ..; of a gradient row = pixel f >> 4
-  // (of 32), output channels 64 ob + 4 (f & 15) ..   (img: image index relative to n_begin)
-  auto load_x = [&](int f, int img, int yy) -> u32x4 {
+  // (of 32), output channels 64 ob + 4 (f & 15) ..
+  auto load_x = [&](int f, int yy) -> u32x4 {
     const int px = f >> 4, c4 = f & 15;
     if constexpr (MODE) {
       // virtual row yy, virtual pixel 32 half + px of parity (py, pq): real row 2 yy + py - 1, real pixel 2 X + pq - 1
-      const int ri = img / hpi, half = img - ri * hpi;
       const int ry = 2 * yy + py - 1, rx = 2 * (32 * half + px) + pq - 1;
       const unsigned okm = 0u - (unsigned)((int)(px < 33) & (int)(ry >= 0) & (int)(ry < p.BH) & (int)(rx >= 0) & (int)(rx < p.BW));
-      const unsigned voff = ((unsigned)(((((ri - r_begin) * p.BH + ry) * p.BW + rx) * p.IP + cbr * 64 + c4 * 4) * 4) & okm) | (OOB & ~okm);
+      const unsigned voff = ((unsigned)((((ri * p.BH + ry) * p.BW + rx) * p.IP + cbr * 64 + c4 * 4) * 4) & okm) | (OOB & ~okm);
       return __builtin_amdgcn_raw_buffer_load_b128(rxb, (int)voff, 0, 0);
     }
     const int gx = px - 1;
     const unsigned okm = 0u - (unsigned)((int)(px < W3_XW) & (int)(yy >= 0) & (int)(yy < GH) & (int)(gx >= 0) & (int)(gx < 32));
-    const unsigned voff = ((unsigned)(((((img - r_begin) * GH + yy) * 32 + gx) * p.IP + cb * 64 + c4 * 4) * 4) & okm) | (OOB & ~okm);
+    const unsigned voff = ((unsigned)((((ri * GH + yy) * 32 + gx) * p.IP + cb * 64 + c4 * 4) * 4) & okm) | (OOB & ~okm);
     return __builtin_amdgcn_raw_buffer_load_b128(rxb, (int)voff, 0, 0);
   };
-  auto load_g = [&](int f, int img, int y) -> u32x4 {
+  auto load_g = [&](int f, int y) -> u32x4 {
     const int px = f >> 4, c = ob * 64 + 4 * (f & 15);
-    const int ri = img / hpi, half = img - ri * hpi;
     const unsigned okm = 0u - (unsigned)((int)(y < GH) & (int)(c < p.OP));
-    const unsigned voff = ((unsigned)(((((ri - r_begin) * GH + y) * p.GW + 32 * half + px) * p.OP + c) * 4) & okm) | (OOB & ~okm);
+    const unsigned voff = ((unsigned)((((ri * GH + y) * p.GW + 32 * half + px) * p.OP + c) * 4) & okm) | (OOB & ~okm);
     return __builtin_amdgcn_raw_buffer_load_b128(rgs, (int)voff, 0, 0);
   };
   float sg = 1.f, sx = 1.f;
   float om = 0.f;      // max |scaled operand| this thread split (ovf_report)
-  if constexpr (NP <= 2) { sg = pow2_scale(p.g_amax); sx = pow2_scale(p.x_amax); }
+  if constexpr (NP <= 2) { sg = pow2_scale(p.g_amax, p.g_amax2); sx = pow2_scale(p.x_amax, p.x_amax2); }
   auto split_store = [&](const u32x4 v, unsigned char* dst, int plane_bytes, float sc) {
     if constexpr (NP == 1) {
       uint2 h2;
@@ -3003,10 +3022,10 @@ __global__ __launch_bounds__(64 * W3_WAVES) void wgrad3_halo_x3_kernel(const Wgr
   // and the last 32 input items to the first 32 threads (each load keeps one buffer descriptor)
   constexpr int NX4 = W3_XW * 16;
   u32x4 st[3];
-  auto load_items = [&](int img, int yx, int yg) {
-    st[0] = load_x(tid, img, yx);
-    st[1] = load_g(tid, img, yg);
-    if (wave == 0) st[2] = load_x(512 + lane, img, yx);       // (lanes 32 .. 63: masked, zeros)
+  auto load_items = [&](int yx, int yg) {
+    st[0] = load_x(tid, yx);
+    st[1] = load_g(tid, yg);
+    if (wave == 0) st[2] = load_x(512 + lane, yx);       // (lanes 32 .. 63: masked, zeros)
   };
   auto store_items = [&](int yx, int yg, bool with_g) {
     store_x(st[0], tid, yx);
@@ -3014,18 +3033,25 @@ __global__ __launch_bounds__(64 * W3_WAVES) void wgrad3_halo_x3_kernel(const Wgr
     if (wave == 0 && lane < NX4 - 512) store_x(st[2], 512 + lane, yx);
   };
   for (int n = n_begin; n < n_end; ++n) {
-    const int img = n;
+    {
+      const bool second = n >= nv1;
+      const int v = second ? n - nv1 - r2_begin * hpi : n - r_begin * hpi;      // (virtual) image within the pair's window
+      ri = v / hpi;
+      half = v - ri * hpi;
+      rgs = second ? rgs2 : rgs1;
+      rxb = second ? rxb2 : rxb1;
+    }
     // prologue of an image: ring rows 0 .. 3 (MODE 0: input rows -1 (zeros), 0, 1, 2) and gradient rows 0, 1; every wave
     // is past the last step of the previous image (its closing barrier)
-    load_items(img, 0 - PADR, 0);
+    load_items(0 - PADR, 0);
     store_items(0 - PADR, 0, true);
-    load_items(img, 1 - PADR, 1);
+    load_items(1 - PADR, 1);
     store_items(1 - PADR, 1, true);
-    load_items(img, 2 - PADR, GH);
+    load_items(2 - PADR, GH);
     store_items(2 - PADR, 0, false);
-    load_items(img, 3 - PADR, GH);
+    load_items(3 - PADR, GH);
     store_items(3 - PADR, 0, false);
-    load_items(img, 4 - PADR, 2);      // staged: ring row 4, gradient row 2
+    load_items(4 - PADR, 2);      // staged: ring row 4, gradient row 2
     __syncthreads();
     for (int y = 0; y < GH; ++y) {
       const unsigned char* Grow = Gp + (y & 1) * W3_GBUF;
@@ -3056,7 +3082,7 @@ __global__ __launch_bounds__(64 * W3_WAVES) void wgrad3_halo_x3_kernel(const Wgr
           // the middle of the step, with the next tap's fragments already loaded, so no wave restarts cold after it.
           __syncthreads();
           store_items(y + 4 - PADR, y + 2, true);
-          load_items(img, y + 5 - PADR, y + 3);
+          load_items(y + 5 - PADR, y + 3);
         }
         if constexpr (NP <= 2) {
 #pragma unroll
@@ -4175,45 +4201,63 @@ extern "C" size_t fcd_wgrad_workspace_bytes(const FcdWgradDesc* d) {
   return (size_t)slabs * d->O * d->KH * d->KW * d->IP * sizeof(float);
 }
 
-// Shapes whose weight gradient can take a second operand pair (fcd_conv_wgrad2): what conv_wgrad_x3p_kernel serves under
-// FCD_PREC_BF16X3 -- more than 32 output channels, no halo form -- with a first pair of whole 32-pixel K-tiles.
+// Shapes whose weight gradient can take a second operand pair (fcd_conv_wgrad2): more than 32 output channels and either
+// the 3 x 3 / 4 x 4 halo form (wgrad3_halo_x3_kernel walks the second pair's images after the first's) or the split-once
+// kernel (conv_wgrad_x3p_kernel, whose K loop takes a second segment) with a first pair of whole 32-pixel K-tiles.
 static bool wgrad2_ok(const FcdWgradDesc* d) {
-  if (d->precision != FCD_PREC_BF16X3 || d->O <= 32 || getenv("FCD_WGRAD_OLD")) return false;
-  if (((long)d->N * d->GH * d->GW) % 32 != 0) return false;
+  const bool f16fam = d->precision == FCD_PREC_F16X2 || d->precision == FCD_PREC_F16;
+  if ((d->precision != FCD_PREC_BF16X3 && !f16fam) || d->O <= 32 || getenv("FCD_WGRAD_OLD")) return false;
+  FcdWgradDesc dd = *d;
+  dd.precision = FCD_PREC_BF16X3;          // (kernels are chosen by shape as under BF16X3, see wgrad_impl)
   int rows, R, nch, halves, ipS;
-  if (halo7_plan(d, &rows, &R, &nch) || halo12w_plan(d, &rows, &R, &nch, &halves) || halo3w_plan(d, &ipS, nullptr, false)) return false;
-  return true;
+  if (halo7_plan(&dd, &rows, &R, &nch) || halo12w_plan(&dd, &rows, &R, &nch, &halves)) return false;
+  if (halo3w_plan(&dd, &ipS, nullptr, f16fam && d->g_amax && d->x_amax)) return !getenv("FCD_NO_WGRAD3_PAIRS");
+  return ((long)d->N * d->GH * d->GW) % 32 == 0;
 }
 extern "C" int fcd_conv_wgrad2_supported(const FcdWgradDesc* d) {
   if (!d || validate_wgrad(d) != FCD_OK) return 0;
   return wgrad2_ok(d) ? 1 : 0;
 }
 
-static int wgrad_impl(const FcdWgradDesc* d, const float* gsmall, const float* xbig, const float* gsmall2,
-                      const float* xbig2, int N2, float* dw, void* workspace, size_t workspace_bytes, void* stream);
+struct WgradPair2 {          // the second operand pair of fcd_conv_wgrad2
+  const float* gs = nullptr;
+  const float* xb = nullptr;
+  int N = 0;
+  const float* g_amax = nullptr;
+  const float* x_amax = nullptr;
+};
+static int wgrad_impl(const FcdWgradDesc* d, const float* gsmall, const float* xbig, const WgradPair2& p2, float* dw,
+                      void* workspace, size_t workspace_bytes, void* stream);
 
 extern "C" int fcd_conv_wgrad(const FcdWgradDesc* d, const float* gsmall, const float* xbig, float* dw,
                               void* workspace, size_t workspace_bytes, void* stream) {
-  return wgrad_impl(d, gsmall, xbig, nullptr, nullptr, 0, dw, workspace, workspace_bytes, stream);
+  return wgrad_impl(d, gsmall, xbig, WgradPair2{}, dw, workspace, workspace_bytes, stream);
 }
 
 extern "C" int fcd_conv_wgrad2(const FcdWgradDesc* d, const float* gsmall, const float* xbig, const float* gsmall2,
-                               const float* xbig2, int N2, float* dw, void* workspace, size_t workspace_bytes, void* stream) {
+                               const float* xbig2, int N2, const float* g_amax2, const float* x_amax2, float* dw,
+                               void* workspace, size_t workspace_bytes, void* stream) {
   FCD_REQUIRE(d != nullptr && gsmall2 && xbig2 && N2 > 0, "wgrad2: the second operand pair");
   FCD_REQUIRE(validate_wgrad(d) == FCD_OK && wgrad2_ok(d),
-              "wgrad2: shape / precision without a two-segment form (fcd_conv_wgrad2_supported)");
-  return wgrad_impl(d, gsmall, xbig, gsmall2, xbig2, N2, dw, workspace, workspace_bytes, stream);
+              "wgrad2: shape / precision without a two-pair form (fcd_conv_wgrad2_supported)");
+  WgradPair2 p2;
+  p2.gs = gsmall2; p2.xb = xbig2; p2.N = N2; p2.g_amax = g_amax2; p2.x_amax = x_amax2;
+  return wgrad_impl(d, gsmall, xbig, p2, dw, workspace, workspace_bytes, stream);
 }
 
-static int wgrad_impl(const FcdWgradDesc* d, const float* gsmall, const float* xbig, const float* gsmall2,
-                      const float* xbig2, int N2, float* dw, void* workspace, size_t workspace_bytes, void* stream) {
+static int wgrad_impl(const FcdWgradDesc* d, const float* gsmall, const float* xbig, const WgradPair2& p2, float* dw,
+                      void* workspace, size_t workspace_bytes, void* stream) {
   FCD_REQUIRE(d != nullptr, "wgrad: null descriptor");
+  const float* gsmall2 = p2.gs;
+  const float* xbig2 = p2.xb;
+  const int N2 = p2.N;
   FcdWgradDesc dd = *d;
   // FCD_PREC_F16X2: the two-plane forms need both maxima; without them (and for the shapes that have no such form)
   // the weight gradient runs as FCD_PREC_BF16X3 -- unlike the convolutions there is no operand format tied to the choice
   // (FCD_PREC_F16: the same kernels with the high pieces only, NP = 1)
   const bool f16fam = d->precision == FCD_PREC_F16X2 || d->precision == FCD_PREC_F16;
-  const bool want_h2 = f16fam && d->g_amax && d->x_amax;
+  // (two pairs: one scale per operand from the larger of the two maxima, so both pairs' are needed)
+  const bool want_h2 = f16fam && d->g_amax && d->x_amax && (!gsmall2 || (p2.g_amax && p2.x_amax));
   const bool onep = d->precision == FCD_PREC_F16;
   if (f16fam) dd.precision = FCD_PREC_BF16X3;
   const float* g_amax = want_h2 ? d->g_amax : nullptr;
@@ -4240,6 +4284,8 @@ static int wgrad_impl(const FcdWgradDesc* d, const float* gsmall, const float* x
   a.P2 = N2 * d->GH * d->GW;
   a.gs2_bytes = (size_t)a.P2 * d->OP * 4;
   a.xb2_bytes = (size_t)N2 * d->BH * d->BW * d->IP * 4;
+  a.N2 = N2;
+  a.g_amax2 = a.x_amax2 = nullptr;
   a.splitk = resolve_wgrad_splitk(&dsum);
   a.ktiles = fcd_cdiv(a.P, 32) + fcd_cdiv(a.P2, 32);
   a.ktiles_per_split = fcd_cdiv(a.ktiles, a.splitk);
@@ -4283,8 +4329,9 @@ static int wgrad_impl(const FcdWgradDesc* d, const float* gsmall, const float* x
                          (size_t)a.P * a.OP * 4, (size_t)a.N * a.BH * a.BW * a.IP * 4);
     }
     rc = fcd_check_launch("conv_wgrad");
-  } else if (int ipS = 0, mode3 = 0, slabs3 = halo3w_plan(d, &ipS, &mode3, want_h2); slabs3) {
-    a.splitk = slabs3;
+  } else if (int ipS = 0, mode3 = 0, slabs3 = halo3w_plan(&dsum, &ipS, &mode3, want_h2); slabs3) {
+    a.splitk = slabs3;                                  // (the images of both pairs are dealt to the splits)
+    if (want_h2 && gsmall2) { a.g_amax2 = p2.g_amax; a.x_amax2 = p2.x_amax; }
     const int ncb = (mode3 ? 4 : 1) * d->IP / 64;
     dim3 grid((d->OP / 64) * ncb, slabs3);
     const size_t gsb = (size_t)a.P * a.OP * 4, xbb = (size_t)a.N * a.BH * a.BW * a.IP * 4;
@@ -4341,6 +4388,8 @@ static int wgrad_impl(const FcdWgradDesc* d, const float* gsmall, const float* x
     // no split-K (the discriminator's 8 M- and 34 M-weight layers: 128 .. 512 pixels against 256 tiles): the kernel
     // writes the parameter layout itself; the transposing reduction of a 134 MB slab cost more than the GEMM
     a.direct = (a.splitk == 1 && !getenv("FCD_NO_WGRAD_DIRECT")) ? 1 : 0;
+    FCD_REQUIRE(!gsmall2 || a.P % 32 == 0, "wgrad2: the first pair's pixels must be whole 32-pixel K-tiles");
+    if (want_h2 && gsmall2) { a.g_amax2 = p2.g_amax; a.x_amax2 = p2.x_amax; }
     if (want_h2 && onep) {
       a.g_amax = g_amax; a.x_amax = x_amax;
       note_kernel("conv_wgrad_x3p_kernel<%d, %d, %d, 1>", bm, bm == 64 ? 2 : 4, bm == 64 ? 4 : 2);

@@ -131,9 +131,7 @@ class Discriminator(nn.Module):
         # pair per layer here, the other takes it into its own launch; whatever is left when backward ends is flushed by
         # a callback.  FCD_MERGE_WGRAD=0: two launches per layer as before (A/B runs).
         self.merge_wgrad = os.environ.get("FCD_MERGE_WGRAD", "1") != "0"
-        self._wgrad_stash = {}        # layer -> [(gz, u, sink)]
-        self._wgrad_flush_queued = False
-        self._wgrad_task = -1         # autograd graph task the stash belongs to
+        self._pairing = ops.WgradPairing()
         self._wmax = WeightMaxima(self._convs)     # max |weight| of the six layers in one launch per optimizer step
 
     def _flat_params(self):
@@ -144,40 +142,21 @@ class Discriminator(nn.Module):
 
     def _stash_wgrad(self, li, gz, u, sink) -> None:
         """Leave layer ``li``'s weight-gradient operands for a later backward pass of the same ``backward()`` call."""
-        task = torch._C._current_graph_task_id()
-        if task != self._wgrad_task:
-            # a new backward call (whatever an aborted earlier one left behind is dropped with its graph)
-            self._wgrad_task, self._wgrad_stash, self._wgrad_flush_queued = task, {}, False
-        self._wgrad_stash.setdefault(li, []).append((gz, u, sink))
-        if not self._wgrad_flush_queued:
-            self._wgrad_flush_queued = True
-            torch.autograd.Variable._execution_engine.queue_callback(self._flush_wgrad_stash)
+        def alone():
+            prec_w = self.precision if self.wgrad_precision is None else self.wgrad_precision
+            wd = self._geoms[li].wgrad_desc(u.shape[0], u.shape[1], u.shape[2], precision=prec_w, accumulate=True)
+            ops.conv_wgrad(wd, gz, u, dw=sink)
+        self._pairing.leave(li, (gz, u, sink), alone)
 
     def _take_wgrad(self, li, wd, x, sink):
         """The operand pair an earlier pass of this backward call left for layer ``li``, if this pass can take it into its
-        own launch (same gradient tensor, same geometry, a two-segment form for ``wd``), else None."""
-        if sink is None or not self._wgrad_stash or self._wgrad_task != torch._C._current_graph_task_id():
+        own launch (same gradient tensor, same geometry, a two-pair form for ``wd``), else None."""
+        if sink is None or not ops.conv_wgrad2_supported(wd):
             return None
-        pend = self._wgrad_stash.get(li)
-        if (pend and len(pend) == 1 and pend[0][2] is sink and tuple(pend[0][1].shape[1:]) == tuple(x.shape[1:])
-                and ops.conv_wgrad2_supported(wd)):
-            del self._wgrad_stash[li]
-            return pend[0]
-        return None
+        return self._pairing.take(li, lambda it: it[2] is sink and tuple(it[1].shape[1:]) == tuple(x.shape[1:]))
 
     def _can_stash_wgrad(self, wd, sink, final: bool, scaled: bool) -> bool:
         return bool(self.merge_wgrad and sink is not None and not final and not scaled and ops.conv_wgrad2_supported(wd))
-
-    def _flush_wgrad_stash(self) -> None:
-        """End of a backward call: operand pairs nobody took are turned into gradients by launches of their own."""
-        self._wgrad_flush_queued = False
-        stash, self._wgrad_stash = self._wgrad_stash, {}
-        prec_w = self.precision if self.wgrad_precision is None else self.wgrad_precision
-        for li, items in stash.items():
-            g = self._geoms[li]
-            for gz, u, sink in items:
-                wd = g.wgrad_desc(u.shape[0], u.shape[1], u.shape[2], precision=prec_w, accumulate=True)
-                ops.conv_wgrad(wd, gz, u, dw=sink)
 
     def forward(self, x):
         if not x.is_cuda:

@@ -253,6 +253,11 @@ class Generator(nn.Module):
         self.precision = L.PREC_F32
         self.wgrad_precision = None          # None: same as precision
         self.wgrad_side_stream = os.environ.get("FCD_SIDE_STREAM", "1") != "0"   # ops.SideWork
+        # One weight-gradient launch per layer for the G step's two passes through the generator (ops.WgradPairing): the
+        # reconstruction pass's backward (autograd runs it first) leaves its operand pairs, the translation pass's takes
+        # them along.  FCD_MERGE_WGRAD=0: two launches per layer (A/B runs).
+        self.merge_wgrad = os.environ.get("FCD_MERGE_WGRAD", "1") != "0"
+        self._pairing = ops.WgradPairing()
         cin = num_channels + c_dim
         mods: List[nn.Module] = []
         plan: List[_Layer] = []
@@ -545,16 +550,27 @@ class _GeneratorFn(torch.autograd.Function):
             h2_w = h2 and prec_w in L.F16_FAMILY
             if needs[p0]:
                 sink = grad_sink(ly.conv.weight, True)     # arena-backed: accumulate into p.grad in place
-                if ly.kind == "conv":
-                    wd = gm.wgrad_desc(n, a_in.shape[1], a_in.shape[2], precision=prec_w, accumulate=sink is not None)
-                    if h2_w:
-                        ops.set_wgrad_amax(wd, dz_amax(), act_amax(li))
-                    dw = side.run(lambda: ops.conv_wgrad(wd, dz, a_in, dw=sink), dz, a_in)
+                # (gsmall, xbig) of the weight gradient: a transposed convolution swaps the roles
+                gs, xb = (dz, a_in) if ly.kind == "conv" else (a_in, dz)
+                wd = gm.wgrad_desc(n, xb.shape[1], xb.shape[2], precision=prec_w, accumulate=sink is not None)
+                mx = None
+                if h2_w:
+                    mx = (dz_amax(), act_amax(li)) if ly.kind == "conv" else (act_amax(li), dz_amax())
+                    ops.set_wgrad_amax(wd, *mx)
+                pairs = mod.merge_wgrad and sink is not None and ops.conv_wgrad2_supported(wd)
+                # the pair another pass of this backward call left for the layer rides in this launch; if none has and
+                # this is not the step's last pass, this one leaves its own (Generator.merge_wgrad)
+                extra = mod._pairing.take(li, lambda it: it[2] is sink and it[1].shape[1:] == xb.shape[1:]
+                                          and (it[3] is None) == (mx is None)) if pairs else None
+                if extra is not None:
+                    dw = side.run(lambda: ops.conv_wgrad2(wd, gs, xb, extra[0], extra[1], dw=sink, amax2=extra[3]),
+                                  gs, xb, *extra[:2], *(extra[3] or ()))
+                elif pairs and not final:
+                    mod._pairing.leave(li, (gs, xb, sink, mx),
+                                       lambda wd=wd, gs=gs, xb=xb, sink=sink: ops.conv_wgrad(wd, gs, xb, dw=sink))
+                    dw = None
                 else:
-                    wd = gm.wgrad_desc(n, dz.shape[1], dz.shape[2], precision=prec_w, accumulate=sink is not None)
-                    if h2_w:
-                        ops.set_wgrad_amax(wd, act_amax(li), dz_amax())
-                    dw = side.run(lambda: ops.conv_wgrad(wd, a_in, dz, dw=sink), dz, a_in)
+                    dw = side.run(lambda: ops.conv_wgrad(wd, gs, xb, dw=sink), gs, xb)
                 if sink is None:
                     grads[p0] = dw
             if final:

@@ -70,6 +70,51 @@ class SideWork:
         self.keep.clear()
 
 
+class WgradPairing:
+    """One weight-gradient launch per layer for the two backward passes of one ``backward()`` call that produce the same
+    parameter gradient (``conv_wgrad2``): the D step's paired real / fake batch and gradient penalty, the G step's two
+    passes through the generator.  Whichever pass autograd runs first leaves its operand pair per layer here
+    (``leave``), the other takes it into its own launch (``take``); whatever is left when the backward call ends is
+    turned into gradients by the launches the leaving pass would have made (an engine callback).  Pairs are tied to
+    the autograd graph task they were left in: what an aborted call left behind is dropped with its graph."""
+
+    def __init__(self):
+        self._stash = {}          # key -> [(item, alone)]
+        self._queued = False
+        self._task = -1
+
+    def empty(self) -> bool:
+        return not self._stash
+
+    def leave(self, key, item, alone) -> None:
+        """``item``: what the taking pass needs (operands, gradient tensor, maxima); ``alone()``: the launch of this pair
+        by itself, for the case that nobody takes it."""
+        task = torch._C._current_graph_task_id()
+        if task != self._task:
+            self._task, self._stash, self._queued = task, {}, False
+        self._stash.setdefault(key, []).append((item, alone))
+        if not self._queued:
+            self._queued = True
+            torch.autograd.Variable._execution_engine.queue_callback(self.flush)
+
+    def take(self, key, match):
+        """The item an earlier pass of this backward call left under ``key`` if ``match(item)``, else None."""
+        if not self._stash or self._task != torch._C._current_graph_task_id():
+            return None
+        pend = self._stash.get(key)
+        if pend and len(pend) == 1 and match(pend[0][0]):
+            del self._stash[key]
+            return pend[0][0]
+        return None
+
+    def flush(self) -> None:
+        self._queued = False
+        stash, self._stash = self._stash, {}
+        for items in stash.values():
+            for _, alone in items:
+                alone()
+
+
 # --------------------------------------------------------------------------- #
 # convolution geometry (host logic; unit-tested on CPU)
 # --------------------------------------------------------------------------- #
@@ -386,9 +431,10 @@ def conv_wgrad2_supported(d: WgradDesc) -> bool:
 
 
 def conv_wgrad2(d: WgradDesc, gsmall: torch.Tensor, xbig: torch.Tensor, gsmall2: torch.Tensor, xbig2: torch.Tensor,
-                dw: Optional[torch.Tensor] = None) -> torch.Tensor:
+                dw: Optional[torch.Tensor] = None, amax2=None) -> torch.Tensor:
     """``conv_wgrad`` over two operand pairs of one geometry (``d.N`` and ``gsmall2.shape[0]`` images) in one pass over
-    ``dw``: ``dw (+)= gsmall^T xbig + gsmall2^T xbig2``."""
+    ``dw``: ``dw (+)= gsmall^T xbig + gsmall2^T xbig2``.  ``amax2``: (max |gsmall2|, max |xbig2|) slot arrays, as
+    ``set_wgrad_amax`` attaches the first pair's to ``d`` (the scaled-fp16 forms need all four)."""
     lib = L.load()
     n2 = gsmall2.shape[0]
     if tuple(gsmall.shape) != (d.N, d.GH, d.GW, d.OP) or tuple(xbig.shape) != (d.N, d.BH, d.BW, d.IP):
@@ -408,8 +454,9 @@ def conv_wgrad2(d: WgradDesc, gsmall: torch.Tensor, xbig: torch.Tensor, gsmall2:
     need = lib.fcd_wgrad_workspace_bytes(C.byref(d))
     d.N = n1
     wp, wn = _ws(need, xbig.device)
-    check(lib.fcd_conv_wgrad2(C.byref(d), ptr(gsmall), ptr(xbig), ptr(gsmall2), ptr(xbig2), n2, ptr(dw), wp, wn, stream()),
-          "conv_wgrad2")
+    ga2, xa2 = (None, None) if amax2 is None else amax2
+    check(lib.fcd_conv_wgrad2(C.byref(d), ptr(gsmall), ptr(xbig), ptr(gsmall2), ptr(xbig2), n2,
+                              _amax_ptr(ga2), _amax_ptr(xa2), ptr(dw), wp, wn, stream()), "conv_wgrad2")
     return dw
 
 

@@ -167,15 +167,19 @@ size_t fcd_wgrad_workspace_bytes(const FcdWgradDesc* d);
 int fcd_conv_wgrad(const FcdWgradDesc* d, const float* gsmall, const float* xbig, float* dw,
                    void* workspace, size_t workspace_bytes, void* stream);
 /* The same with a SECOND operand pair of the same geometry (N2 images): dw (+)= gsmall^T xbig + gsmall2^T xbig2 in one
- * pass over dw -- the K axis (pixels) of the split-once kernel runs through both pairs.  What torch's autograd does with
+ * pass over dw -- the K axis (pixels / images) of the kernel runs through both pairs.  What torch's autograd does with
  * two `AccumulateGrad`s into one parameter (the discriminator's weight gradients of the paired real / fake batch and of
- * the gradient penalty, fcd_solver.py:286-299): one read-modify-write of the gradient instead of two.  Only where
- * fcd_conv_wgrad2_supported(d) is 1 (FCD_PREC_BF16X3, more than 32 output channels, no halo form, N GH GW a multiple
- * of 32); workspace: fcd_wgrad_workspace_bytes of the descriptor with N + N2 images.  No reference counterpart as an
- * interface (the reference's two backward passes each call cuDNN's weight gradient). */
+ * the gradient penalty, fcd_solver.py:286-299; the generator's of its two passes per G step, fcd_solver.py:341-365): one
+ * read-modify-write of the gradient -- and one slab reduction -- instead of two.  Only where fcd_conv_wgrad2_supported(d)
+ * is 1: more than 32 output channels, FCD_PREC_BF16X3 or the FCD_PREC_F16 family, and either the 3 x 3 / 4 x 4 halo form
+ * or N GH GW a multiple of 32 (split-once kernel).  g_amax2 / x_amax2: the second pair's maxima, as d->g_amax / d->x_amax
+ * are the first's (the scaled-fp16 forms take one scale per operand from the larger of the two; NULL: the bf16 x 3 form,
+ * as when d's are NULL).  Workspace: fcd_wgrad_workspace_bytes of the descriptor with N + N2 images.  No reference
+ * counterpart as an interface (the reference's two backward passes each call cuDNN's weight gradient). */
 int fcd_conv_wgrad2_supported(const FcdWgradDesc* d);
 int fcd_conv_wgrad2(const FcdWgradDesc* d, const float* gsmall, const float* xbig, const float* gsmall2,
-                    const float* xbig2, int N2, float* dw, void* workspace, size_t workspace_bytes, void* stream);
+                    const float* xbig2, int N2, const float* g_amax2, const float* x_amax2, float* dw,
+                    void* workspace, size_t workspace_bytes, void* stream);
 
 /* Parameter layout [O][I][KH][KW]  ->  gather-form operand [O][KH][KW][IP]. */
 int fcd_pack_weight_fwd(const float* w, float* packed, int O, int I, int IP, int KH, int KW,

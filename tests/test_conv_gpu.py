@@ -1231,3 +1231,59 @@ def test_wgrad_two_operand_pairs(dev, shape):
     # shapes and precisions without the two-segment form say so
     assert not ops.conv_wgrad2_supported(g.wgrad_desc(n1, h, w, precision=0))
     assert not ops.conv_wgrad2_supported(ops.ConvGeom(16, I, 4, 2, 1).wgrad_desc(n1, h, w, precision=2))
+
+
+# (kernel size, O, I, n1, n2, small h, small w): shapes whose two-pair weight gradient takes the halo kernel; image counts
+# chosen so that a split's image range straddles the boundary between the pairs
+W3_PAIR_SHAPES = [(3, 128, 128, 100, 100, 8, 32),     # 3 x 3: three images per split, split 33 = images 99, 100 (pair 2's first), 101
+                  (3, 256, 256, 5, 11, 32, 32),       # the residual blocks' geometry, one image per split, uneven pairs
+                  (4, 128, 64, 31, 21, 8, 32),        # 4 x 4 stride 2: two images per split, an odd first pair
+                  (4, 64, 64, 40, 41, 8, 64)]         # 64-pixel gradient rows: three 32-column halves per split
+
+
+@pytest.mark.parametrize("fam", [pytest.param((2, 2e-6, b""), id="fp32x3"), pytest.param((3, 1e-6, b"<2"), id="fp32x2"),
+                                 pytest.param((4, 1e-3, b"<1"), id="fp16")])
+@pytest.mark.parametrize("shape", W3_PAIR_SHAPES)
+def test_wgrad_two_operand_pairs_halo(dev, shape, fam):
+    """fcd_conv_wgrad2 on the halo kernel (3 x 3 stride 1 and 4 x 4 stride 2; the generator's two backward passes of a G
+    step): the second pair's images follow the first's in the splits' image ranges, the scaled-fp16 forms take one scale
+    per operand from the larger of the two pairs' maxima (the pairs differ by 8x and 1/4x here).  Against torch in float64
+    and against two accumulating single-pair calls."""
+    from fcd_amd import _lib as L, ops
+    k, O, I, n1, n2, h, w = shape
+    prec, tol, tag = fam
+    g = ops.ConvGeom(O, I, k, 1, 1) if k == 3 else ops.ConvGeom(O, I, 4, 2, 1)
+    s = 1 if k == 3 else 2
+    gen = torch.Generator().manual_seed(67)
+    xs = [torch.randn(n, I, s * h, s * w, generator=gen) * sc for n, sc in ((n1, 1.0), (n2, 0.25))]
+    gys = [torch.randn(n, O, h, w, generator=gen) * sc for n, sc in ((n1, 0.01), (n2, 0.08))]
+    xd = [to_nhwc(x, g.IP).to(dev) for x in xs]
+    gd = [to_nhwc(gy, g.OP).to(dev) for gy in gys]
+
+    def desc(n, j, acc=False):
+        d = g.wgrad_desc(n, s * h, s * w, precision=prec, accumulate=acc)
+        return ops.set_wgrad_amax(d, ops.absmax(gd[j]), ops.absmax(xd[j])) if prec >= 3 else d
+
+    mx2 = (ops.absmax(gd[1]), ops.absmax(xd[1])) if prec >= 3 else None
+    d = desc(n1, 0)
+    assert ops.conv_wgrad2_supported(d)
+    got = ops.conv_wgrad2(d, gd[0], xd[0], gd[1], xd[1], amax2=mx2)
+    kern = L.load().fcd_last_conv_kernel()
+    if k == 3 or prec >= 3:
+        assert kern.startswith(b"wgrad3_halo_x3_kernel" + tag), kern
+    else:
+        assert kern.startswith(b"conv_wgrad_x3p_kernel"), kern      # (4 x 4 under bf16 x 3: the split-once kernel's two segments)
+    ref = sum(torch.nn.grad.conv2d_weight(x.double(), (O, I, k, k), gy.double(), stride=s, padding=1) for x, gy in zip(xs, gys))
+    assert relerr(got.cpu(), ref) <= tol
+    two = ops.conv_wgrad(desc(n1, 0), gd[0], xd[0])
+    ops.conv_wgrad(desc(n2, 1, True), gd[1], xd[1], dw=two)
+    assert relerr(got, two) <= 2 * tol
+    base = float(ref.abs().max()) * 0.5
+    acc = torch.full_like(got, base)
+    ops.conv_wgrad2(desc(n1, 0, True), gd[0], xd[0], gd[1], xd[1], dw=acc, amax2=mx2)
+    assert relerr(acc.cpu() - base, ref) <= 10 * tol
+    if prec >= 3:
+        # without the second pair's maxima there is no common scale: the bf16 x 3 form of the same kernels
+        alt = ops.conv_wgrad2(desc(n1, 0), gd[0], xd[0], gd[1], xd[1])
+        assert relerr(alt.cpu(), ref) <= 2e-6
+        ops.check_overflow(dev)

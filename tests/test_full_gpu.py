@@ -157,13 +157,46 @@ def test_full_d_step_arena_merged_weight_gradients(full, prec, monkeypatch):
             loss.backward()
         monkeypatch.setattr(ops, "conv_wgrad2", orig)
         calls[merged] = n2[0]
-        assert not s.D._wgrad_stash                      # nothing left behind
+        assert s.D._pairing.empty()                      # nothing left behind
         if merged:
             print("full D-step, arena, merged weight gradients", prec, ": worst error / bar =", check_grads(s.D, "d", sc, prec, "_arena_merged"))
         grads[merged] = {n: p.grad.clone() for n, p in s.D.named_parameters()}
     assert calls[True] == 6 and calls[False] == 0        # every layer of D took the two-pair launch
     for n in grads[True]:
         assert relerr(grads[True][n], grads[False][n]) <= 5e-6, n
+
+
+@pytest.mark.parametrize("prec", ["fp32x2", "fp32x3"])
+def test_full_g_step_arena_merged_weight_gradients(full, prec, monkeypatch):
+    """The training path of the G step: the weight gradients of the two passes through the generator (translation and
+    reconstruction) of every 3 x 3 and 4 x 4 layer in ONE launch over two operand pairs (fcd_conv_wgrad2 on the halo
+    kernel, Generator.merge_wgrad), accumulated straight into the arena.  Same parity bars against the fp64 oracle as
+    the autograd path; against the two-launch form only the order of fp32 sums (and, under fp32x2, the common scale of
+    the two pairs) differs."""
+    from fcd_amd import ops
+    sc, make, b, alpha = full
+    grads, calls = {}, {}
+    for merged in (True, False):
+        s = make(prec)
+        s.optimizers()
+        s.G.merge_wgrad = merged
+        s.D.requires_grad_(False)
+        s.global_step = s.n_critic - 1
+        n2 = [0]
+        orig = ops.conv_wgrad2
+        monkeypatch.setattr(ops, "conv_wgrad2", lambda *a, **k: (n2.__setitem__(0, n2[0] + 1), orig(*a, **k))[1])
+        loss = s.training_step(b, 0, 1)
+        with s.arenas[1].accumulating():
+            loss.backward()
+        monkeypatch.setattr(ops, "conv_wgrad2", orig)
+        calls[merged] = n2[0]
+        assert s.G._pairing.empty()                      # nothing left behind
+        if merged:
+            print("full G-step, arena, merged weight gradients", prec, ": worst error / bar =", check_grads(s.G, "g", sc, prec, "_arena_merged"))
+        grads[merged] = {n: p.grad.clone() for n, p in s.G.named_parameters()}
+    assert calls[True] == 16 and calls[False] == 0       # all but the two 7 x 7 layers
+    for n in grads[True]:
+        assert relerr(grads[True][n], grads[False][n]) <= 2e-5, n
 
 
 def test_full_steps_with_scaled_fp16_discriminator(full):
