@@ -315,6 +315,8 @@ class _DBackwardFn(torch.autograd.Function):
                 if bsink is None:
                     grads[2 * li + 1] = bs if gz.shape[3] == g.O else bs[: g.O].contiguous()
                 if final:
+                    if mod._pairing.pending(li):      # (a pair left behind that this pass could not take)
+                        side.run(lambda: mod._pairing.drain(li))
                     hook.param_ready(cv.bias)
                     hook.param_ready(cv.weight)
             if li == 0:
@@ -397,6 +399,8 @@ class _DBackwardFn(torch.autograd.Function):
             if needs[2 * li + 1] and grad_sink(mod._convs[li].bias, True) is None:
                 out[2 * li + 1] = torch.zeros_like(mod._convs[li].bias)
             if final:
+                if mod._pairing.pending(li):          # (a pair left behind that this pass could not take)
+                    side.run(lambda: mod._pairing.drain(li))
                 hook.param_ready(mod._convs[li].weight)
                 hook.param_ready(mod._convs[li].bias)
             d = g.fwd_desc(n, u.shape[1], u.shape[2], precision=prec, mask_slope=mod._slopes[li])

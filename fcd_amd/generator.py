@@ -574,6 +574,9 @@ class _GeneratorFn(torch.autograd.Function):
                 if sink is None:
                     grads[p0] = dw
             if final:
+                # (a pair left behind that this pass could not take goes out before the gradient is declared final)
+                if mod._pairing.pending(li):
+                    side.run(lambda: mod._pairing.drain(li))
                 hook.param_ready(ly.conv.weight)
             # data gradient
             if li == 0:

@@ -107,6 +107,15 @@ class WgradPairing:
             return pend[0][0]
         return None
 
+    def pending(self, key) -> bool:
+        return bool(self._stash) and key in self._stash and self._task == torch._C._current_graph_task_id()
+
+    def drain(self, key) -> None:
+        """Launch, each by itself, whatever is still left under ``key`` (a pass about to declare the gradient final)."""
+        if self._stash and self._task == torch._C._current_graph_task_id():
+            for _, alone in self._stash.pop(key, ()):
+                alone()
+
     def flush(self) -> None:
         self._queued = False
         stash, self._stash = self._stash, {}

@@ -160,3 +160,49 @@ def test_on_before_batch_transfer_and_oracle_patch_batch():
     assert np.array_equal(xs[0][:, 2:, :-1], x0[0][:, :-2, 1:])
     assert (xs[0][:, :2, :] == -1.0).all() and (xs[0][:, :, -1] == -1.0).all()
     assert (ms[0][:2] == 0).all() and np.array_equal(ms[0][2:, :-1], m0[0][:-2, 1:])
+
+
+def test_wgrad_pairing_protocol():
+    """ops.WgradPairing (host logic of the one-launch weight gradients): within one backward() call the node that runs
+    first leaves its item, the second takes it; an item nobody takes is launched by itself when the call ends; a
+    mismatching taker leaves it alone; drain() launches a key's leftovers at once; a new call starts clean."""
+    import torch
+    from fcd_amd.ops import WgradPairing
+    pairing, log = WgradPairing(), []
+
+    class Node(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, tag, mode):
+            ctx.tag, ctx.mode = tag, mode
+            return x * 1.0
+
+        @staticmethod
+        def backward(ctx, g):
+            if ctx.mode == "drain":
+                assert pairing.pending("w")
+                pairing.drain("w")
+                assert not pairing.pending("w")
+                return g, None, None
+            got = pairing.take("w", lambda it: ctx.mode != "mismatch") if ctx.mode != "leave-only" else None
+            if got is not None:
+                log.append(("pair", got, ctx.tag))
+            else:
+                pairing.leave("w", ctx.tag, lambda t=ctx.tag: log.append(("alone", t)))
+            return g, None, None
+
+    def run(modes):
+        log.clear()
+        x = torch.ones(3, requires_grad=True)
+        y = x
+        for i, m in enumerate(modes):          # node i+1 consumes node i: autograd runs the LAST one first
+            y = Node.apply(y, i, m)
+        y.sum().backward()
+        assert pairing.empty()
+        return list(log)
+
+    assert run(["any", "any"]) == [("pair", 1, 0)]                                   # second pass takes the first's pair
+    assert run(["any"]) == [("alone", 0)]                                            # a lone pass: flushed at the end
+    assert run(["any", "any", "any"]) == [("pair", 2, 1), ("alone", 0)]              # the third finds nothing, leaves, is flushed
+    assert run(["mismatch", "any"]) == [("alone", 1), ("alone", 0)]                  # refused by the taker: both go alone
+    assert run(["any", "drain", "any"]) == [("alone", 2), ("alone", 0)]              # drained before the last node runs
+    assert not pairing.pending("w") and pairing.take("w", lambda it: True) is None   # outside backward: nothing
