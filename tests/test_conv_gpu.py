@@ -1238,7 +1238,8 @@ def test_wgrad_two_operand_pairs(dev, shape):
 W3_PAIR_SHAPES = [(3, 128, 128, 100, 100, 8, 32),     # 3 x 3: three images per split, split 33 = images 99, 100 (pair 2's first), 101
                   (3, 256, 256, 5, 11, 32, 32),       # the residual blocks' geometry, one image per split, uneven pairs
                   (4, 128, 64, 31, 21, 8, 32),        # 4 x 4 stride 2: two images per split, an odd first pair
-                  (4, 64, 64, 40, 41, 8, 64)]         # 64-pixel gradient rows: three 32-column halves per split
+                  (4, 64, 64, 40, 41, 8, 64),         # 64-pixel gradient rows: three 32-column halves per split
+                  (4, 128, 64, 9, 7, 8, 16)]          # 16-pixel rows: no halo form, the split-once kernel's two segments in every precision
 
 
 @pytest.mark.parametrize("fam", [pytest.param((2, 2e-6, b""), id="fp32x3"), pytest.param((3, 1e-6, b"<2"), id="fp32x2"),
@@ -1269,10 +1270,11 @@ def test_wgrad_two_operand_pairs_halo(dev, shape, fam):
     assert ops.conv_wgrad2_supported(d)
     got = ops.conv_wgrad2(d, gd[0], xd[0], gd[1], xd[1], amax2=mx2)
     kern = L.load().fcd_last_conv_kernel()
-    if k == 3 or prec >= 3:
+    if w >= 32 and (k == 3 or prec >= 3):
         assert kern.startswith(b"wgrad3_halo_x3_kernel" + tag), kern
     else:
-        assert kern.startswith(b"conv_wgrad_x3p_kernel"), kern      # (4 x 4 under bf16 x 3: the split-once kernel's two segments)
+        # (4 x 4 under bf16 x 3, or rows the halo kernel does not take: the split-once kernel's two segments)
+        assert kern.startswith(b"conv_wgrad_x3p_kernel") and kern.endswith({2: b"3>", 3: b"2>", 4: b"1>"}[prec]), kern
     ref = sum(torch.nn.grad.conv2d_weight(x.double(), (O, I, k, k), gy.double(), stride=s, padding=1) for x, gy in zip(xs, gys))
     assert relerr(got.cpu(), ref) <= tol
     two = ops.conv_wgrad(desc(n1, 0), gd[0], xd[0])
