@@ -130,7 +130,7 @@ class Discriminator(nn.Module):
         # paired batch's backward and the gradient penalty's backward-of-backward autograd runs first leaves its operand
         # pair per layer here, the other takes it into its own launch; whatever is left when backward ends is flushed by
         # a callback.  FCD_MERGE_WGRAD=0: two launches per layer as before (A/B runs).
-        self.merge_wgrad = os.environ.get("FCD_MERGE_WGRAD", "1") != "0"
+        self.merge_wgrad = os.environ.get("FCD_MERGE_WGRAD_D", os.environ.get("FCD_MERGE_WGRAD", "1")) != "0"
         self._pairing = ops.WgradPairing()
         self._wmax = WeightMaxima(self._convs)     # max |weight| of the six layers in one launch per optimizer step
 

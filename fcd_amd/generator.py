@@ -256,7 +256,12 @@ class Generator(nn.Module):
         # One weight-gradient launch per layer for the G step's two passes through the generator (ops.WgradPairing): the
         # reconstruction pass's backward (autograd runs it first) leaves its operand pairs, the translation pass's takes
         # them along.  FCD_MERGE_WGRAD=0: two launches per layer (A/B runs).
-        self.merge_wgrad = os.environ.get("FCD_MERGE_WGRAD", "1") != "0"
+        self.merge_wgrad = os.environ.get("FCD_MERGE_WGRAD_G", os.environ.get("FCD_MERGE_WGRAD", "1")) != "0"
+        # ... for launches of at most this many GFLOP per pass: a pair that waits for the second pass is weight-gradient
+        # work the first pass's side stream does not do beside its norm backwards.  With 100 us launches (the benchmarked
+        # size: 34-39 GFLOP) the saved slab reduction and launch outweigh that (-0.16 ms per step); with 3 ms launches
+        # (the stress size: 1.1-1.2 TFLOP) they do not (+2 %, tools/stress_probe.py).
+        self.merge_wgrad_max_gflop = float(os.environ.get("FCD_MERGE_WGRAD_MAX_GFLOP", "200"))
         self._pairing = ops.WgradPairing()
         cin = num_channels + c_dim
         mods: List[nn.Module] = []
@@ -557,7 +562,8 @@ class _GeneratorFn(torch.autograd.Function):
                 if h2_w:
                     mx = (dz_amax(), act_amax(li)) if ly.kind == "conv" else (act_amax(li), dz_amax())
                     ops.set_wgrad_amax(wd, *mx)
-                pairs = mod.merge_wgrad and sink is not None and ops.conv_wgrad2_supported(wd)
+                pairs = (mod.merge_wgrad and sink is not None and ops.conv_wgrad2_supported(wd)
+                         and 2e-9 * wd.N * wd.GH * wd.GW * wd.O * wd.I * wd.KH * wd.KW <= mod.merge_wgrad_max_gflop)
                 # the pair another pass of this backward call left for the layer rides in this launch; if none has and
                 # this is not the step's last pass, this one leaves its own (Generator.merge_wgrad)
                 extra = mod._pairing.take(li, lambda it: it[2] is sink and it[1].shape[1:] == xb.shape[1:]
