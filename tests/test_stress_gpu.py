@@ -154,6 +154,11 @@ def test_f16x2_halo_kernels_over_2gib(dev, shape):
     dw2 = ops.conv_wgrad(wdesc(h), gy[:h].contiguous(), x[:h].contiguous()).double() + \
         ops.conv_wgrad(wdesc(h), gy[h:].contiguous(), x[h:].contiguous()).double()
     assert float((dw.double() - dw2).norm() / dw2.norm()) <= 1e-5
+    # two operand pairs in one launch (fcd_conv_wgrad2), each beyond 2 GiB: the second pair's windows start at its own
+    # first image of every split (here the same tensors again: twice the gradient)
+    both = ops.conv_wgrad2(wdesc(N), gy, x, gy, x, amax2=(ga, xa))
+    assert L.load().fcd_last_conv_kernel() == kernel
+    assert float((both.double() - 2 * dw.double()).norm() / (2 * dw.double()).norm()) <= 1e-5
     ops.check_overflow(dev)
 
 
