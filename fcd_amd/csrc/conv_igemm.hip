@@ -393,10 +393,13 @@ constexpr int ah_maxpx(int bm) { return bm == 256 ? 396 : 264; }   // (4 + 2) x 
 // 256 x 64 tile (8 x 1 waves of 32 x 64: one fragment read per MFMA, LDS-read-bound) into the 256 x 128 tile's
 // 4 x 2 waves of 64 x 64 (two reads per three MFMAs).  blockIdx.y = py.
 template <int BM, int BN, int WM, int WN, int S, int PREC, bool N16 = false, bool BPRE = false, bool AH = false, int NP = 3,
-          bool RS = false, bool PP = false>
+          bool RS = false, bool PP = false, bool S2D = false>
 __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const GatherArgs p, const size_t in_bytes,
                                                                        const unsigned w_bytes) {
   static_assert(!PP || (AH && BPRE && BM == 256 && BN == 128 && WM == 4 && WN == 2 && S == 3), "PP shape");
+  static_assert(!S2D || (AH && BPRE && !PP && BM == 256 && BN == 128), "S2D shape");
+  // S2D: the kernel's view of a 4 x 4 stride-2 pad-1 convolution -- 2 x 2 taps over 4 Cin virtual channels (p, q, c)
+  const int KHv = S2D ? 2 : p.KH, KWv = S2D ? 2 : p.KW, CinV = S2D ? 4 * p.Cin : p.Cin;
   static_assert(!N16 || (BN == 32 && WN == 1 && PREC == FCD_PREC_F32), "N16 shape");
   constexpr int BNC = N16 ? 16 : BN;            // output channels this block computes
   constexpr int NW = WM * WN, NT = 64 * NW;     // 4 waves (one per SIMD) or 8 (two per SIMD)
@@ -502,9 +505,22 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
   // K-tile number q covers k = 32q.. in that order, or - tap_inner - tap q % T of channel slice
   // q / T: all taps of a 32-channel slice back to back, so that the up-to-T re-reads of an input
   // line are a few K-tiles apart and hit in L2 instead of a whole channel sweep apart.
-  const int T = p.KH * p.KW;
+  const int T = KHv * KWv;
   int k, tap, ci;
-  if (BPRE || p.tap_inner) {
+  // S2D: slice cs = (32-channel block cr = cs / 4, parity (py, pq) = cs % 4) of the virtual channels -- the four parities
+  // of a channel block back to back, so that, like the per-tap kernel, all sixteen taps of 32 channels are summed before
+  // the next 32 are touched -- and virtual tap (th, tw): the weights' K index is that of real tap (2 th + py, 2 tw + pq),
+  // channels 32 cr ..
+  int s2d_cs = 0;
+  auto s2d_k = [&](int cs, int th_, int tw_) {
+    const int par = cs & 3, cr = cs >> 2;
+    return ((2 * th_ + (par >> 1)) * 4 + 2 * tw_ + (par & 1)) * p.Cin + cr * 32 + kc * 4;
+  };
+  if constexpr (S2D) {
+    tap = 0;
+    ci = kc * 4;
+    k = s2d_k(0, 0, 0);
+  } else if (BPRE || p.tap_inner) {
     tap = kt0 % T;
     ci = (kt0 / T) * 32 + kc * 4;
     k = tap * p.Cin + ci;
@@ -513,7 +529,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
     tap = k / p.Cin;
     ci = k - tap * p.Cin;
   }
-  int th = tap / p.KW, tw = tap - th * p.KW;
+  int th = tap / KWv, tw = tap - th * KWv;
 
   // Every lane issues exactly AL + BL DMA instructions per K-tile with full EXEC (the counted
   // vmcnt below relies on it), so validity is folded into the offset with pure ALU selects.
@@ -547,7 +563,16 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
     }
   };
   auto issue_advance = [&]() {
-    if constexpr (BPRE) {
+    if constexpr (S2D) {
+      tw += 1;
+      const bool ww = tw == 2;
+      tw = ww ? 0 : tw;
+      th += ww ? 1 : 0;
+      const bool wh = th == 2;
+      th = wh ? 0 : th;
+      s2d_cs += wh ? 1 : 0;
+      k = s2d_k(s2d_cs, th, tw);      // (slices past the last one: only in dummy issues, whose offsets are forced out of range)
+    } else if constexpr (BPRE) {
       // (BPRE implies 32-channel slices, so the taps-inner order always applies, T = 1 included.)
       // Branch-free on purpose: one basic block with the MFMAs around it, so that the scheduler can
       // spread this bookkeeping between them instead of running it as a VALU-only tail (-1.4 %).
@@ -782,7 +807,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
     // (KH x KW taps at stride 1 on a GW-wide grid, 3 x 3 with pad 1 or the 2 x 2 taps of one phase of a 4 x 4 stride-2
     //  adjoint with pad 0 / 1: the halo region has KH - 1 extra rows and KW - 1 extra columns)
     // (PP: the union of the pair's regions, pad_w = 1 and 0: one more column)
-    const int W2 = p.GW + p.KW - 1 + (PP ? 1 : 0), APX = (BM / p.GW + p.KH - 1) * W2, PB = APX * 64;   // halo row pitch, halo pixels, plane bytes
+    const int W2 = p.GW + KWv - 1 + (PP ? 1 : 0), APX = (BM / p.GW + KHv - 1) * W2, PB = APX * 64;   // halo row pitch, halo pixels, plane bytes
     const int ah_y0 = (tm * BM - n0 * ghw) / p.GW;                          // first output row of this tile in its image
     int hbase[TM];                                                          // halo pixel of this lane's rows at tap (0, 0)
     constexpr int NLH = (AH_MAXPX * 8 + NT - 1) / NT;                       // float4 of a slice per thread (7)
@@ -801,10 +826,22 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
 #pragma unroll
       for (int j = 0; j < NLH; ++j) {
         const int f = tid + NT * j, hp = f >> 3, c4 = f & 7;
-        const int hy = hp / W2, hx = hp - hy * W2, iy = ah_y0 - pad_h + hy, ix = hx - pad_w;
-        const unsigned okm = 0u - (unsigned)((int)(hp < APX) & (int)(cs * 32 < p.Cin) & (int)(iy >= 0) & (int)(iy < p.IH) &
+        const int hy = hp / W2, hx = hp - hy * W2;
+        int iy, ix, cblk;
+        if constexpr (S2D) {
+          // virtual pixel (Y, X) of parity (py, pq) = real pixel (2 Y + py - 1, 2 X + pq - 1), zero outside the image
+          const int par = cs & 3;
+          cblk = cs >> 2;
+          iy = 2 * (ah_y0 + hy) + (par >> 1) - 1;
+          ix = 2 * hx + (par & 1) - 1;
+        } else {
+          iy = ah_y0 - pad_h + hy;
+          ix = hx - pad_w;
+          cblk = cs;
+        }
+        const unsigned okm = 0u - (unsigned)((int)(hp < APX) & (int)(cs * 32 < CinV) & (int)(iy >= 0) & (int)(iy < p.IH) &
                                              (int)(ix >= 0) & (int)(ix < p.IW));
-        const unsigned voff = ((unsigned)(((iy * p.IW + ix) * p.Cin + cs * 32 + c4 * 4) * 4) & okm) | (OOB & ~okm);
+        const unsigned voff = ((unsigned)(((iy * p.IW + ix) * p.Cin + cblk * 32 + c4 * 4) * 4) & okm) | (OOB & ~okm);
         hst[j] = __builtin_amdgcn_raw_buffer_load_b128(rinb, (int)voff, 0, 0);
       }
     };
@@ -1052,11 +1089,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
         stage = next;
       };
       int it = 0;
-      for (int cs = 0; cs * 32 < p.Cin; ++cs) {
+      for (int cs = 0; cs * 32 < CinV; ++cs) {
         int toff = 0, twc = 0;
         for (int t9 = 0; t9 < T - 1; ++t9) {
-          const bool wrap = twc == p.KW - 1;
-          const int toff_next = toff + (wrap ? W2 - (p.KW - 1) : 1);
+          const bool wrap = twc == KWv - 1;
+          const int toff_next = toff + (wrap ? W2 - (KWv - 1) : 1);
           body(std::false_type{}, it, toff, toff_next, cs);
           toff = toff_next;
           twc = wrap ? 0 : twc + 1;
@@ -3681,6 +3718,25 @@ bool gather_ahalo(const FcdConvDesc* d, int rows) {
   return d->GH % (rows / d->GW) == 0;
 }
 
+// The space-to-depth A-halo form (template flag S2D) of a 4 x 4, stride-2, pad-1 convolution (the generator's two
+// down-sampling layers, the forward form of the data gradient of its up-sampling ones): with
+// S[p][q][Y][X] = x[2Y + p - 1][2X + q - 1] the layer is a 2 x 2-tap stride-1 convolution over the 4 Cin virtual channels
+// (p, q, c), so a 32-channel slice of one parity is fetched and split once per workgroup and its four taps read shifted,
+// where the per-tap kernel fetches (by LDS-DMA) and splits the activation tile once per tap.  Same operands (the weights'
+// K index of virtual tap (a, b), parity (p, q) is that of real tap (2a + p, 2b + q)); the K order differs from the per-tap
+// kernel's, so results agree to rounding, not bit for bit.  FCD_NO_S2D=1: A/B runs.
+bool gather_s2d(const FcdConvDesc* d) {
+  if (getenv("FCD_NO_S2D")) return false;
+  if (!gather_big_tile(d)) return false;
+  int bm, bn;
+  gather_tile(d, bm, bn);
+  if (bn != 128 || d->KH != 4 || d->KW != 4 || d->istride != 2 || d->ostride != 1 || d->nphase != 1) return false;
+  if (d->pad_h[0] != 1 || d->pad_w[0] != 1 || d->ooff_h[0] || d->ooff_w[0]) return false;
+  if (d->IH != 2 * d->GH || d->IW != 2 * d->GW || d->OH != d->GH || d->OW != d->GW) return false;
+  if (d->GW != 32 && d->GW != 64) return false;
+  return d->GH % (256 / d->GW) == 0;
+}
+
 // The phase-pair form (template flag PP) of the A-halo kernel: the four 2 x 2-tap phases of a stride-2 adjoint with at
 // most 64 output channels, two phases (py, 0) / (py, 1) per workgroup on the 256 x 128 tile's wave layout.  Taken when
 // the 256 x 64 A-halo launch would be and the halved grid still covers the chip.  FCD_NO_PP=1: A/B runs.
@@ -3809,6 +3865,13 @@ int run_gather(const FcdConvDesc* d, GatherArgs& a, hipStream_t st) {
       a.tiles_m = fcd_cdiv(a.M, 256);
       grid = dim3(a.tiles_m * a.tiles_n, a.nphase * a.splitk);
       if (bn == 128 && gather_ahalo(d, 256)) FCD_LAUNCH_PRESPLIT(256, 128, 4, 2, 3, true);
+      else if (bn == 128 && gather_s2d(d)) {
+        const int np = h2 ? (a.onep ? 1 : 2) : 3;
+        note_kernel("conv_gather_dma_kernel<256, 128 (space to depth), 4, 2, 3, 2, false, true, true, %d>", np);
+        if (np == 1) hipLaunchKernelGGL((conv_gather_dma_kernel<256, 128, 4, 2, 3, X3, false, true, true, 1, false, false, true>), grid, dim3(512), 0, st, a, in_bytes, w_bytes);
+        else if (np == 2) hipLaunchKernelGGL((conv_gather_dma_kernel<256, 128, 4, 2, 3, X3, false, true, true, 2, false, false, true>), grid, dim3(512), 0, st, a, in_bytes, w_bytes);
+        else hipLaunchKernelGGL((conv_gather_dma_kernel<256, 128, 4, 2, 3, X3, false, true, true, 3, false, false, true>), grid, dim3(512), 0, st, a, in_bytes, w_bytes);
+      }
       else if (bn == 128) FCD_LAUNCH_PRESPLIT(256, 128, 4, 2, 2, false);
       else if (h2 && gather_pp(d)) {     // (the three-plane instance spills on this tile: scaled-fp16 forms only)
         // two phases per workgroup: the 256 x 128 tile's 4 x 2 waves of 64 x 64, wave column = phase column

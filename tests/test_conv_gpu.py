@@ -1289,3 +1289,61 @@ def test_wgrad_two_operand_pairs_halo(dev, shape, fam):
         alt = ops.conv_wgrad2(desc(n1, 0), gd[0], xd[0], gd[1], xd[1])
         assert relerr(alt.cpu(), ref) <= 2e-6
         ops.check_overflow(dev)
+
+
+# (O, I, N, small h, small w): 4 x 4 stride-2 pad-1 forward convolutions that take the space-to-depth A-halo form
+S2D_GEOMS = [(128, 64, 32, 64, 64),       # the generator's 64 -> 128 down-sampling layer at a paired call's 32 samples
+             (256, 128, 32, 32, 32),      # its 128 -> 256 layer: two column tiles
+             (160, 96, 17, 64, 64),       # ragged output channels (the second column tile is a quarter full), 3 slices per parity
+             (128, 32, 89, 24, 32)]       # one slice per parity, 24 rows per image (three row tiles), an odd tile count (267)
+
+
+@pytest.mark.parametrize("fam", [pytest.param((2, 2e-6, b"3>"), id="fp32x3"), pytest.param((3, 1e-6, b"2>"), id="fp32x2"),
+                                 pytest.param((4, 1e-3, b"1>"), id="fp16")])
+@pytest.mark.parametrize("geom", S2D_GEOMS)
+def test_gather_space_to_depth(dev, geom, fam, monkeypatch):
+    """4 x 4 stride-2 pad-1 convolutions through the A-halo kernel's space-to-depth form (template flag S2D: 2 x 2 taps over
+    the input's four parities as 4 Cin virtual channels; a 32-channel slice of one parity fetched and split once per
+    workgroup): against torch in float64 with bias + LeakyReLU in the epilogue, the fused InstanceNorm statistics of the
+    plain convolution against float64, and everything against the per-tap kernel (FCD_NO_S2D=1; another K order, so to
+    rounding)."""
+    from fcd_amd import _lib as L, ops
+    O, I, N, h, w = geom
+    prec, tol, tag = fam
+    g = ops.ConvGeom(O, I, 4, 2, 1)
+    gen = torch.Generator().manual_seed(71)
+    wt = torch.randn(O, I, 4, 4, generator=gen) / (4 * I ** 0.5)
+    x = torch.randn(N, I, 2 * h, 2 * w, generator=gen)
+    x.view(-1)[::50021] *= 300.0
+    b = torch.randn(O, generator=gen)
+    wd, xd = wt.to(dev), to_nhwc(x, g.IP).to(dev)
+    wa, xa = ops.absmax(wd), ops.absmax(xd)
+
+    def desc(**kw):
+        d = g.fwd_desc(N, 2 * h, 2 * w, precision=prec, **kw)
+        return ops.set_amax(d, xa, wa) if prec >= 3 else d
+
+    fmt = ops.weight_format(desc())
+    assert fmt == (2 if prec >= 3 else 1)
+    wp = ops.pack_weight_fwd_h2(wd, g, wa) if fmt == 2 else ops.pack_weight_fwd_x3(wd, g)
+
+    def run():
+        out = ops.conv_gather(desc(act_slope=0.01), xd, wp, bias=b.to(dev))
+        k = L.load().fcd_last_conv_kernel()
+        z, mean, rstd, varu = ops.conv_gather_stats(desc(), xd, wp, want_var=True)
+        return out, z, mean, rstd, varu, k
+
+    new = run()
+    assert b"(space to depth)" in new[5] and new[5].endswith(b"true, " + tag[:1] + b">"), new[5]
+    monkeypatch.setenv("FCD_NO_S2D", "1")
+    old = run()
+    assert b"(space to depth)" not in old[5], old[5]
+    ref = F.conv2d(x.double(), wt.double(), None, 2, 1)
+    assert relerr(from_nhwc(new[0].cpu(), O).double(), F.leaky_relu(ref + b.double().view(1, -1, 1, 1), 0.01)) <= tol
+    assert relerr(from_nhwc(new[1].cpu(), O).double(), ref) <= tol
+    assert relerr(new[2].cpu().double()[:, :O], ref.mean(dim=(2, 3))) <= 20 * tol
+    assert relerr(new[4].cpu().double()[:, :O], ref.var(dim=(2, 3), unbiased=True)) <= 20 * tol
+    for a_, b_ in zip(new[:5], old[:5]):
+        assert relerr(a_, b_) <= 2 * tol
+    if prec >= 3:
+        ops.check_overflow(dev)

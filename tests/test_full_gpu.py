@@ -56,8 +56,15 @@ BIG = np.load(os.path.join(GOLD, "full_grad_samples.npz"))
 #     few elements by O(1) of their value in either fp32 evaluation (worst ratio 9.8, D features.1.0.weight).
 # The measured errors of every tensor are written to gpurun_out/full_parity_*.json.
 # Round 3: the split-operand modes' bars tightened to what they need (worst measured ratios: 0.83 fp32x2 G step, 1.18
-# fp32x3 D step norm-wise; 2.0 element-wise): 1.25 and 2.5.
-FACTORS = {"fp32x3": (1.25, 2.5), "fp32x2": (1.25, 2.5), "fp32": (2.0, 12.0)}
+# fp32x3 D step norm-wise; 2.0 element-wise): 1.25 and 2.5 -- and the element-wise one set back to 3.0 at the end of the
+# round, on this evidence: one ReLU mask element of residual block main.9 sits on its kink in fp64, and the G step's
+# worst element-wise ratio is 1.8-2.0 when an evaluation leaves it on fp64's side and 2.80-2.81 (main.9.main.1.bias, both
+# modes) when it does not.  Which of the two happens changes with the order of fp32 sums in a kernel five layers earlier:
+# three forms of the generator's 4 x 4 stride-2 convolutions, each within 1e-6 of float64 in tests/test_conv_gpu.py (per
+# tap; space to depth with the parities outermost; space to depth with the channel blocks outermost, the one kept), gave
+# 1.81 / 2.80 / 2.00 under fp32x2 and 0.89 / <= 1.63 / 2.81 under fp32x3 (tools/parity_lottery.sh).  Norm-wise nothing
+# moved: G step <= 0.92, D step 0.004 ... 1.18 of the reference's own fp32 error, as before.
+FACTORS = {"fp32x3": (1.25, 3.0), "fp32x2": (1.25, 3.0), "fp32": (2.0, 12.0)}
 OUT_DIR = os.path.join(os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(__file__))), "gpurun_out")
 
 
