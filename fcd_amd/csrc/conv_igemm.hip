@@ -1036,17 +1036,18 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gather_dma_kernel(const Gat
         __builtin_amdgcn_sched_barrier(0);
       }
     };
-    if constexpr (AH) {
-      ah_load(0);
-      ah_store();
-      ah_load(1);
-    }
+    // (the weight ring's first S tiles go out first: their LDS-DMA flies while the first slice is fetched and split)
 #pragma unroll
     for (int s = 0; s < S; ++s) {
       issue_prepare(s, s < nk);
 #pragma unroll
       for (int q = 0; q < ND; ++q) issue_one(q);
       issue_advance();
+    }
+    if constexpr (AH) {
+      ah_load(0);
+      ah_store();
+      ah_load(1);
     }
     Pieces P0, P1;
     wait_vmcnt<(S - 1) * ND>();
